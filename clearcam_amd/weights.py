@@ -1,0 +1,207 @@
+"""State-dict plumbing: key names, seeded synthetic weights, safetensors loading.
+
+The reference downloads ``yolov9-{size}.safetensors`` and
+``CLIP-ViT-L-14-laion2B-s32B-b82K.safetensors`` at construction
+(``detection/yolov9.py:372``, ``models/objects.py:91``).  There is no network
+here, so every test/bench uses a *seeded synthetic* state dict with exactly the
+reference's key names and shapes; real files drop in
+through :func:`load_safetensors`.
+
+The generator uses ``numpy.random.Generator(PCG64(seed))`` only, so the same
+weights come out in this container and on the GPU box.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .arch import CLIP_L14, YOLO_ARCH, ClipArch, YoloArch
+
+# ----------------------------------------------------------------------------------------------
+# YOLOv9 key/shape enumeration (detection/yolov9.py attribute tree)
+# ----------------------------------------------------------------------------------------------
+
+ConvSpec = Tuple[str, int, int, int, int, bool]  # (prefix, cin, cout, k, groups, is_bare_conv2d)
+
+
+def _conv(prefix: str, cin: int, cout: int, k: int, g: int = 1) -> ConvSpec:
+    return (prefix + ".conv", cin, cout, k, g, False)
+
+
+def _repncsp(prefix: str, cin: int, hid: int, n: int) -> List[ConvSpec]:
+    out = [_conv(f"{prefix}.cv1", cin, hid, 1), _conv(f"{prefix}.cv2", cin, hid, 1),
+           _conv(f"{prefix}.cv3", 2 * hid, 2 * hid, 1)]
+    for j in range(n):
+        out += [_conv(f"{prefix}.m.list.{j}.cv1", hid, hid, 3), _conv(f"{prefix}.m.list.{j}.cv2", hid, hid, 3)]
+    return out
+
+
+def _elan4(prefix: str, cin: int, hid: int, cout: int, n: int) -> List[ConvSpec]:
+    out = [_conv(f"{prefix}.cv1", cin, 4 * hid, 1)]
+    for br in ("cv2", "cv3"):
+        out += _repncsp(f"{prefix}.{br}.list.0", 2 * hid, hid, n)
+        out += [_conv(f"{prefix}.{br}.list.1", 2 * hid, 2 * hid, 3)]
+    out += [_conv(f"{prefix}.cv4", 8 * hid, cout, 1)]
+    return out
+
+
+def _down(prefix: str, kind: str, cin: int, cout: int) -> List[ConvSpec]:
+    if kind == "adown":
+        assert cin == cout
+        return [_conv(f"{prefix}.cv1", cin // 2, cout // 2, 3), _conv(f"{prefix}.cv2", cin // 2, cout // 2, 1)]
+    return [_conv(f"{prefix}.cv1", cin, cout, 3)]
+
+
+def yolo_conv_specs(a: YoloArch) -> List[ConvSpec]:
+    """Every conv of the t/s/m/c graph in state-dict order of appearance."""
+    P = "model.list."
+    s: List[ConvSpec] = []
+    s += [_conv(P + "0", 3, a.stem, 3), _conv(P + "1", a.stem, 2 * a.stem, 3)]
+    if a.b2_kind == "elan1":
+        h = a.b2_hidden
+        s += [_conv(P + "2.cv1", 2 * a.stem, h, 1), _conv(P + "2.cv2", h // 2, h // 2, 3),
+              _conv(P + "2.cv3", h // 2, h // 2, 3), _conv(P + "2.cv4", 2 * h, a.b2_out, 1)]
+    else:
+        s += _elan4(P + "2", 2 * a.stem, a.b2_hidden, a.b2_out, a.rep_n)
+    s += _down(P + "3", a.down_kind, a.b2_out, a.d3_out)
+    s += _elan4(P + "4", a.d3_out, a.e4_hidden, a.b4_out, a.rep_n)
+    s += _down(P + "5", a.down_kind, a.b4_out, a.d5_out)
+    s += _elan4(P + "6", a.d5_out, a.e6_hidden, a.p4, a.rep_n)
+    s += _down(P + "7", a.down_kind, a.p4, a.d7_out)
+    s += _elan4(P + "8", a.d7_out, a.e8_hidden, a.p5, a.rep_n)
+    s += [_conv(P + "9.cv1", a.p5, a.spp_hidden, 1), _conv(P + "9.cv5", 4 * a.spp_hidden, a.p5, 1)]
+    s += _elan4(P + "12", a.p5 + a.p4, a.e6_hidden, a.p4, a.rep_n)
+    s += _elan4(P + "15", a.p4 + a.b4_out, a.e4_hidden, a.p3, a.rep_n)
+    s += _down(P + "16", a.down_kind, a.p3, a.d16_out)
+    s += _elan4(P + "18", a.d16_out + a.p4, a.e6_hidden, a.p4, a.rep_n)
+    s += _down(P + "19", a.down_kind, a.p4, a.d19_out)
+    s += _elan4(P + "21", a.d19_out + a.p5, a.e8_hidden, a.p5, a.rep_n)
+    H = P + "22."
+    for lvl, cin in enumerate((a.p3, a.p4, a.p5)):
+        s += [_conv(f"{H}cv2.list.{lvl}.list.0", cin, 64, 3), _conv(f"{H}cv2.list.{lvl}.list.1", 64, 64, 3, 4),
+              (f"{H}cv2.list.{lvl}.list.2", 64, 64, 1, 4, True)]
+        s += [_conv(f"{H}cv3.list.{lvl}.list.0", cin, a.cls_hidden, 3),
+              _conv(f"{H}cv3.list.{lvl}.list.1", a.cls_hidden, a.cls_hidden, 3),
+              (f"{H}cv3.list.{lvl}.list.2", a.cls_hidden, a.nc, 1, 1, True)]
+    return s
+
+
+def yolo_param_count(size: str) -> int:
+    n = 16  # dfl
+    for _, cin, cout, k, g, _ in yolo_conv_specs(YOLO_ARCH[size]):
+        n += cout * (cin // g) * k * k + cout
+    return n
+
+
+_SCALES = None
+
+
+def _synth_scales(size: str) -> Dict[str, float]:
+    global _SCALES
+    if _SCALES is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(__file__), "assets", "synth_scales.json")) as f:
+            _SCALES = json.load(f)
+    return _SCALES[size]
+
+
+def synthetic_yolov9_state_dict(size: str = "c", seed: int = 1234, scales=None) -> Dict[str, np.ndarray]:
+    """Seeded state dict with the reference's key names (OIHW f32 weights, f32 biases).
+
+    weight = N(0, 1/fan_in) * scale[conv]; the per-conv scale table (assets/synth_scales.json,
+    produced once by tools/calibrate_synth.py) keeps every pre-activation at std ~1 through the
+    144-conv SiLU stack, and class-logit biases of about -5 let a few dozen anchors clear the 0.25
+    threshold so top-300 / mask-NMS get real work.  Deterministic: PCG64(seed) + committed table.
+    """
+    a = YOLO_ARCH[size]
+    if scales is None:
+        scales = _synth_scales(size)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd: Dict[str, np.ndarray] = {}
+    for prefix, cin, cout, k, g, bare in yolo_conv_specs(a):
+        fan_in = (cin // g) * k * k
+        w = rng.standard_normal((cout, cin // g, k, k), dtype=np.float32)
+        # zero-sum filters: SiLU outputs have a positive mean, and without normalisation layers
+        # that DC term swamps the spatial signal after a few dozen convs
+        w -= w.mean(axis=(1, 2, 3), keepdims=True, dtype=np.float64).astype(np.float32)
+        w *= np.float32(scales.get(prefix, 1.0) / math.sqrt(fan_in))
+        b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+        if bare and cout == a.nc:
+            b = (rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.5) - np.float32(5.0)).astype(np.float32)
+        sd[prefix + ".weight"] = w.astype(np.float32)
+        sd[prefix + ".bias"] = b.astype(np.float32)
+    sd["model.list.22.dfl.conv.weight"] = np.arange(16, dtype=np.float32).reshape(1, 16, 1, 1)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# CLIP
+# ----------------------------------------------------------------------------------------------
+
+def clip_shapes(a: ClipArch = CLIP_L14) -> Dict[str, Tuple[int, ...]]:
+    """Key -> shape for the OpenCLIP state dict (``models/objects.py:29-89``)."""
+    W, T = a.v_width, a.t_width
+    s: Dict[str, Tuple[int, ...]] = {
+        "visual_conv1.weight": (W, 3, a.patch, a.patch),
+        "class_embedding": (W,),
+        "positional_embedding": (a.v_tokens, W),
+        "ln_pre.weight": (W,), "ln_pre.bias": (W,),
+        "ln_post.weight": (W,), "ln_post.bias": (W,),
+        "proj": (W, a.embed),
+        "token_embedding.weight": (a.t_vocab, T),
+        "positional_embedding_text": (a.t_ctx, T),
+        "ln_final.weight": (T,), "ln_final.bias": (T,),
+        "text_projection": (T, a.embed),
+    }
+    for i in range(a.v_layers):
+        p = f"resblocks_img.{i}."
+        s.update({p + "ln_1.weight": (W,), p + "ln_1.bias": (W,), p + "ln_2.weight": (W,), p + "ln_2.bias": (W,),
+                  p + "in_proj_weight": (3 * W, W), p + "in_proj_bias": (3 * W,),
+                  p + "out_proj_weight": (W, W), p + "out_proj_bias": (W,),
+                  p + "mlp_c_fc.weight": (a.v_mlp, W), p + "mlp_c_fc.bias": (a.v_mlp,),
+                  p + "mlp_c_proj.weight": (W, a.v_mlp), p + "mlp_c_proj.bias": (W,)})
+    for i in range(a.t_layers):
+        p = f"resblocks.{i}."
+        s.update({p + "ln_1.weight": (T,), p + "ln_1.bias": (T,), p + "ln_2.weight": (T,), p + "ln_2.bias": (T,),
+                  p + "in_proj_weight": (3 * T, T), p + "in_proj_bias": (3 * T,),
+                  p + "attn_out_proj_weight": (T, T), p + "attn_out_proj_bias": (T,),
+                  p + "mlp_c_fc.weight": (a.t_mlp, T), p + "mlp_c_fc.bias": (a.t_mlp,),
+                  p + "mlp_c_proj.weight": (T, a.t_mlp), p + "mlp_c_proj.bias": (T,)})
+    return s
+
+
+def synthetic_clip_state_dict(a: ClipArch = CLIP_L14, seed: int = 4321) -> Dict[str, np.ndarray]:
+    """Seeded CLIP state dict (transformer-style init: N(0, 0.02)-ish matrices, LN gain 1)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd: Dict[str, np.ndarray] = {}
+    for k, shp in clip_shapes(a).items():
+        if k.endswith("ln_1.weight") or k.endswith("ln_2.weight") or k in ("ln_pre.weight", "ln_post.weight", "ln_final.weight"):
+            v = 1.0 + 0.1 * rng.standard_normal(shp, dtype=np.float32)
+        elif k.endswith(".bias") or k.endswith("_bias"):
+            v = 0.02 * rng.standard_normal(shp, dtype=np.float32)
+        elif len(shp) == 1:
+            v = 0.05 * rng.standard_normal(shp, dtype=np.float32)
+        elif k == "visual_conv1.weight":
+            v = rng.standard_normal(shp, dtype=np.float32) / math.sqrt(shp[1] * shp[2] * shp[3])
+        elif "positional" in k or k == "token_embedding.weight":
+            v = 0.05 * rng.standard_normal(shp, dtype=np.float32)
+        elif k in ("proj", "text_projection"):
+            v = rng.standard_normal(shp, dtype=np.float32) / math.sqrt(shp[0])
+        else:  # (out, in) linear weights
+            v = rng.standard_normal(shp, dtype=np.float32) * (0.7 / math.sqrt(shp[1]))
+        sd[k] = v.astype(np.float32)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# real weights
+# ----------------------------------------------------------------------------------------------
+
+def load_safetensors(path: str) -> Dict[str, np.ndarray]:
+    """Load a reference checkpoint (same key names) as float32 numpy arrays."""
+    from safetensors.numpy import load_file
+    return {k: np.ascontiguousarray(v, dtype=np.float32) if v.dtype != np.float32 else v
+            for k, v in load_file(path).items()}

@@ -1,0 +1,303 @@
+"""ORACLE (test infrastructure, not product code): CPU fp32 restatement of the reference detector.
+
+Restates ``detection/yolov9.py`` (whole file) and ``utils/helpers.py:127-131`` (``resize``) of
+roryclear/clearcam in PyTorch-CPU float32 + numpy integer arithmetic.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the
+product path (``clearcam_amd``) never does.
+
+PARITY UNPINNED: the reference stores no detections/boxes anywhere (``test/tracks.pkl`` and
+``test/tracker_inputs.pkl`` are missing blobs), tinygrad (pinned ``fe39cf14``, not vendored) cannot
+be imported here, and no weights exist offline — so this restatement cannot be checked against the
+reference's own outputs.  What *is* pinned: parameter count 25.29 M / 51.07 GMAC for size "c"
+(the YOLOv9 paper's figures), the state-dict key set and the integer
+letterbox arithmetic (tests/test_oracle_yolo.py).  tinygrad semantics taken from SURVEY.md
+Appendix B: uint8 ``lerp`` fixed point, zero letterbox padding, ``avg_pool2d`` count_include_pad,
+``max_pool2d`` -inf padding, stable descending top-k.  One third-party detail cannot be verified
+offline: tinygrad may lower ``x / c`` to ``x * (1/c)``; this restatement divides (<= 1 ulp apart).
+
+Every function cites the reference lines it follows.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from clearcam_amd.arch import YOLO_ARCH, YoloArch
+
+MAX_DET = 300
+CONF_THRESHOLD = 0.25
+IOU_THRESHOLD = 0.45
+
+
+# ----------------------------------------------------------------------------------------------
+# letterbox  (detection/yolov9.py:390-404, utils/helpers.py:127-131, tinygrad interpolate/lerp)
+# ----------------------------------------------------------------------------------------------
+
+def letterbox_geometry(h: int, w: int, res: int, stride: int = 32) -> Tuple[int, int, int, int]:
+    """(new_h, new_w, pad_y, pad_x) exactly as ``YOLOv9.preprocess`` computes them (:390-403)."""
+    r = min(res / h, res / w)
+    new_w, new_h = int(round(w * r)), int(round(h * r))
+    dw, dh = (res - new_w) % stride, (res - new_h) % stride
+    dw, dh = dw / 2, dh / 2
+    return new_h, new_w, int(round(dh - 0.1)), int(round(dw - 0.1))
+
+
+def interp_axis_tables(n_in: int, n_out: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """low, high, frac for one axis of ``Tensor.interpolate(mode='linear', align_corners=False)``.
+
+    index = clip(scale*(i+0.5)-0.5, 0, n_in-1) evaluated in float32 (Appendix B-1)."""
+    scale = np.float32(n_in / n_out)
+    arr = np.arange(n_out, dtype=np.float32)
+    idx = (scale * (arr + np.float32(0.5))) - np.float32(0.5)
+    idx = np.clip(idx, np.float32(0), np.float32(n_in - 1)).astype(np.float32)
+    low = np.floor(idx).astype(np.int32)
+    high = np.ceil(idx).astype(np.int32)
+    frac = (idx - np.floor(idx)).astype(np.float32)
+    return low, high, frac
+
+
+def _lerp_u8(a: np.ndarray, b: np.ndarray, frac: np.ndarray) -> np.ndarray:
+    """tinygrad ``Tensor.lerp`` for uint8: 7-bit fixed point with int8-wrapped difference."""
+    w = (frac * np.float32(128) + np.float32(0.5)).astype(np.int16)            # truncating cast
+    d = (b.astype(np.uint8) - a.astype(np.uint8)).astype(np.uint8).view(np.int8).astype(np.int16)
+    t = (d * w + np.int16(64)).astype(np.int16).view(np.uint16) >> np.uint16(7)
+    return (a.astype(np.uint16) + t).astype(np.uint8)
+
+
+def resize_bilinear(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
+    """``helpers.resize`` (:127-131): separable, W axis first then H, no antialias, dtype kept."""
+    assert img.ndim == 3
+    lw, hw, fw = interp_axis_tables(img.shape[1], new_w)
+    lh, hh, fh = interp_axis_tables(img.shape[0], new_h)
+    if img.dtype == np.uint8:
+        x = _lerp_u8(img[:, lw, :], img[:, hw, :], fw[None, :, None])
+        x = _lerp_u8(x[lh, :, :], x[hh, :, :], fh[:, None, None])
+        return x
+    x = img.astype(np.float32)
+    a, b = x[:, lw, :], x[:, hw, :]
+    x = a + (b - a) * fw[None, :, None]
+    a, b = x[lh, :, :], x[hh, :, :]
+    x = a + (b - a) * fh[:, None, None]
+    return x.astype(img.dtype)
+
+
+def letterbox(frame: np.ndarray, res: int) -> np.ndarray:
+    """``YOLOv9.preprocess`` (:390-404): resize + symmetric zero pad (HWC, dtype preserved)."""
+    h, w = frame.shape[:2]
+    nh, nw, py, px = letterbox_geometry(h, w, res)
+    img = resize_bilinear(frame, nh, nw)
+    return np.pad(img, ((py, py), (px, px), (0, 0)))
+
+
+# ----------------------------------------------------------------------------------------------
+# graph  (detection/yolov9.py:33-155, 298-326)
+# ----------------------------------------------------------------------------------------------
+
+class YOLOv9Oracle:
+    """``YOLOv9(size, res)`` for sizes t/s/m/c with an explicit state dict (no download)."""
+
+    def __init__(self, size: str, res: int, state_dict: Dict[str, np.ndarray]):
+        self.arch: YoloArch = YOLO_ARCH[size]
+        self.res = res
+        self.sd = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in state_dict.items()}
+
+    # -- primitive blocks ---------------------------------------------------------------------
+    def _conv2d(self, x, name, stride=1, groups=1):
+        w = self.sd[name + ".weight"]
+        return F.conv2d(x, w, self.sd[name + ".bias"], stride=stride, padding=w.shape[-1] // 2, groups=groups)
+
+    def conv(self, x, name, stride=1, groups=1):
+        """``Conv.__call__`` :33-38 — conv + bias then SiLU."""
+        return F.silu(self._conv2d(x, name + ".conv", stride, groups))
+
+    def adown(self, x, p):  # :40-52
+        x = F.avg_pool2d(x, 2, 1, 0, False, True)
+        x1, x2 = x.chunk(2, 1)
+        x1 = self.conv(x1, p + ".cv1", stride=2)
+        x2 = F.max_pool2d(x2, 3, 2, 1)
+        x2 = self.conv(x2, p + ".cv2")
+        return torch.cat((x1, x2), 1)
+
+    def aconv(self, x, p):  # :54-63
+        return self.conv(F.avg_pool2d(x, 2, 1, 0, False, True), p + ".cv1", stride=2)
+
+    def down(self, x, p):
+        return self.adown(x, p) if self.arch.down_kind == "adown" else self.aconv(x, p)
+
+    def elan1(self, x, p):  # :65-80
+        y = list(self.conv(x, p + ".cv1").chunk(2, 1))
+        y.append(self.conv(y[-1], p + ".cv2"))
+        y.append(self.conv(y[-1], p + ".cv3"))
+        return self.conv(torch.cat(y, 1), p + ".cv4")
+
+    def repncsp(self, x, p):  # :82-105
+        x2 = self.conv(x, p + ".cv1")
+        for j in range(self.arch.rep_n):
+            q = f"{p}.m.list.{j}"
+            x2 = x2 + self.conv(self.conv(x2, q + ".cv1"), q + ".cv2")
+        return self.conv(torch.cat((x2, self.conv(x, p + ".cv2")), 1), p + ".cv3")
+
+    def elan4(self, x, p):  # :107-125
+        x = self.conv(x, p + ".cv1")
+        y0, y1 = x.chunk(2, 1)
+        y2 = self.conv(self.repncsp(y1, p + ".cv2.list.0"), p + ".cv2.list.1")
+        y3 = self.conv(self.repncsp(y2, p + ".cv3.list.0"), p + ".cv3.list.1")
+        return self.conv(torch.cat((y0, y1, y2, y3), 1), p + ".cv4")
+
+    def sppelan(self, x, p):  # :127-149
+        y = [self.conv(x, p + ".cv1")]
+        for _ in range(3):
+            y.append(F.max_pool2d(y[-1], 5, 1, 2))
+        return self.conv(torch.cat(y, 1), p + ".cv5")
+
+    @staticmethod
+    def upsample(x):  # :285-292
+        return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+    # -- backbone + neck ----------------------------------------------------------------------
+    def features(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """Blocks 0..21 (:304-325); returns [P3, P4, P5] = outputs of blocks 15, 18, 21."""
+        P = "model.list."
+        y: Dict[int, torch.Tensor] = {}
+        y[0] = self.conv(x, P + "0", stride=2)
+        y[1] = self.conv(y[0], P + "1", stride=2)
+        y[2] = self.elan1(y[1], P + "2") if self.arch.b2_kind == "elan1" else self.elan4(y[1], P + "2")
+        y[3] = self.down(y[2], P + "3")
+        y[4] = self.elan4(y[3], P + "4")
+        y[5] = self.down(y[4], P + "5")
+        y[6] = self.elan4(y[5], P + "6")
+        y[7] = self.down(y[6], P + "7")
+        y[8] = self.elan4(y[7], P + "8")
+        y[9] = self.sppelan(y[8], P + "9")
+        y[12] = self.elan4(torch.cat((self.upsample(y[9]), y[6]), 1), P + "12")
+        y[15] = self.elan4(torch.cat((self.upsample(y[12]), y[4]), 1), P + "15")
+        y[18] = self.elan4(torch.cat((self.down(y[15], P + "16"), y[12]), 1), P + "18")
+        y[21] = self.elan4(torch.cat((self.down(y[18], P + "19"), y[9]), 1), P + "21")
+        self.block_outputs = y
+        return [y[15], y[18], y[21]]
+
+    # -- head ---------------------------------------------------------------------------------
+    def head_raw(self, feats: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """``DDetect`` branches (:202-207): per level (B,144,H,W) = cat(box 64, cls 80)."""
+        H = "model.list.22."
+        out = []
+        for i, x in enumerate(feats):
+            b = f"{H}cv2.list.{i}.list."
+            c = f"{H}cv3.list.{i}.list."
+            x0 = self._conv2d(self.conv(self.conv(x, b + "0"), b + "1", groups=4), b + "2", groups=4)
+            x1 = self._conv2d(self.conv(self.conv(x, c + "0"), c + "1"), c + "2")
+            out.append(torch.cat((x0, x1), 1))
+        return out
+
+    def decode(self, raw: Sequence[torch.Tensor]) -> torch.Tensor:
+        """``DDetect`` decode (:209-220), ``make_anchors`` :247-261, ``DFL`` :273-282,
+        ``dist2bbox`` :263-271 -> (B, 84, A)."""
+        B = raw[0].shape[0]
+        anchors, strides = [], []
+        for x, s in zip(raw, (8, 16, 32)):
+            h, w = x.shape[2:]
+            sx = (torch.arange(w, dtype=torch.float32) + 0.5).reshape(1, -1).repeat(h, 1).reshape(-1)
+            sy = (torch.arange(h, dtype=torch.float32) + 0.5).reshape(-1, 1).repeat(1, w).reshape(-1)
+            anchors.append(torch.stack((sx, sy), -1))
+            strides.append(torch.full((h * w,), float(s)))
+        anchors = torch.cat(anchors).t().unsqueeze(0)      # (1, 2, A)
+        strides = torch.cat(strides).unsqueeze(0)          # (1, A)
+        cat = torch.cat([x.reshape(B, 144, -1) for x in raw], 2)
+        box, cls = cat.split((64, 80), 1)
+        a = box.shape[2]
+        prob = box.reshape(B, 4, 16, a).transpose(2, 1).softmax(1)
+        dist = F.conv2d(prob, self.sd["model.list.22.dfl.conv.weight"]).reshape(B, 4, a)
+        lt, rb = dist.chunk(2, 1)
+        x1y1, x2y2 = anchors - lt, anchors + rb
+        dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * strides
+        return torch.cat((dbox, torch.sigmoid(cls)), 1)
+
+    # -- postprocess --------------------------------------------------------------------------
+    @staticmethod
+    def postprocess(output: torch.Tensor, max_det=MAX_DET, conf=CONF_THRESHOLD, iou_thr=IOU_THRESHOLD) -> torch.Tensor:
+        """``postprocess`` :439-458 with ``compute_iou_matrix`` :423-437.  (B,84,A) -> (B,300,6).
+
+        top-k is *stable* descending (ties -> lower anchor index first), which is how tinygrad's
+        sort breaks ties (Appendix B-7 calls the order implementation-defined)."""
+        xc, yc, w, h, scores = output[:, 0], output[:, 1], output[:, 2], output[:, 3], output[:, 4:]
+        x1, y1, x2, y2 = xc - w / 2, yc - h / 2, xc + w / 2, yc + h / 2
+        cls = scores.argmax(1)
+        probs = scores.max(1).values
+        probs = torch.where(probs >= conf, probs, torch.zeros_like(probs))
+        boxes = torch.stack((x1, y1, x2, y2, probs, cls.float()), 2)
+        order = torch.sort(probs, dim=1, descending=True, stable=True).indices[:, :max_det]
+        boxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 6))
+        bx1, by1, bx2, by2 = boxes[..., 0], boxes[..., 1], boxes[..., 2], boxes[..., 3]
+        areas = (bx2 - bx1) * (by2 - by1)
+        ix1 = torch.maximum(bx1[:, :, None], bx1[:, None, :])
+        iy1 = torch.maximum(by1[:, :, None], by1[:, None, :])
+        ix2 = torch.minimum(bx2[:, :, None], bx2[:, None, :])
+        iy2 = torch.minimum(by2[:, :, None], by2[:, None, :])
+        inter = (ix2 - ix1).clamp_min(0) * (iy2 - iy1).clamp_min(0)
+        ious = inter / (areas[:, :, None] + areas[:, None, :] - inter)
+        ious = torch.triu(ious, diagonal=1)
+        same = boxes[..., 5][:, :, None] == boxes[..., 5][:, None, :]
+        keep = ((ious > iou_thr) & same).sum(1) == 0
+        return boxes * keep.unsqueeze(-1)
+
+    @staticmethod
+    def scale_boxes(lb_hw: Tuple[int, int], preds: torch.Tensor, src_hw: Tuple[int, int]) -> torch.Tensor:
+        """``scale_boxes``/``clip_boxes`` :406-421 (applied to zero rows too)."""
+        gain = min(lb_hw[0] / src_hw[0], lb_hw[1] / src_hw[1])
+        pad_x = (lb_hw[1] - src_hw[1] * gain) / 2
+        pad_y = (lb_hw[0] - src_hw[0] * gain) / 2
+        p = preds.clone()
+        p[..., [0, 2]] = ((p[..., [0, 2]] - np.float32(pad_x)) / np.float32(gain)).clamp(0, src_hw[1])
+        p[..., [1, 3]] = ((p[..., [1, 3]] - np.float32(pad_y)) / np.float32(gain)).clamp(0, src_hw[0])
+        return p
+
+    # -- call surfaces ------------------------------------------------------------------------
+    def network_input(self, frames: np.ndarray) -> torch.Tensor:
+        """(B,H,W,3) BGR u8/f32 -> letterboxed RGB NCHW /255 (:376-379)."""
+        lb = np.stack([letterbox(f, self.res) for f in frames])
+        x = torch.from_numpy(np.ascontiguousarray(lb[..., ::-1])).permute(0, 3, 1, 2)
+        return x.to(torch.float32) / 255.0
+
+    @torch.no_grad()
+    def detect_batch(self, frames: np.ndarray) -> np.ndarray:
+        """Batch extension of ``__call__``: (B,H,W,3) -> (B,300,6); B=1 is the reference."""
+        x = self.network_input(frames)
+        y = self.decode(self.head_raw(self.features(x)))
+        preds = self.postprocess(y)
+        return self.scale_boxes(tuple(x.shape[2:]), preds, frames.shape[1:3]).numpy()
+
+    def __call__(self, frame: np.ndarray) -> np.ndarray:
+        """``YOLOv9.__call__`` :375-388: (H,W,3) BGR -> (300,6) [x1,y1,x2,y2,conf,cls]."""
+        return self.detect_batch(frame[None])[0]
+
+
+def match_detections(ref: np.ndarray, got: np.ndarray, iou_thr: float = 0.9):
+    """Parity metric: rows with score>0 matched greedily by class + IoU.
+
+    Returns (n_ref, n_got, n_matched, max_abs_box_err, max_abs_score_err) over matched pairs."""
+    r = ref[ref[:, 4] > 0]
+    g = got[got[:, 4] > 0]
+    used = np.zeros(len(g), bool)
+    n, box_err, sc_err = 0, 0.0, 0.0
+    for row in r:
+        best, bj = -1.0, -1
+        for j, c in enumerate(g):
+            if used[j] or int(c[5]) != int(row[5]):
+                continue
+            ix = max(0.0, min(row[2], c[2]) - max(row[0], c[0]))
+            iy = max(0.0, min(row[3], c[3]) - max(row[1], c[1]))
+            inter = ix * iy
+            u = (row[2] - row[0]) * (row[3] - row[1]) + (c[2] - c[0]) * (c[3] - c[1]) - inter
+            iou = inter / u if u > 0 else (1.0 if np.allclose(row[:4], c[:4]) else 0.0)
+            if iou > best:
+                best, bj = iou, j
+        if bj >= 0 and best >= iou_thr:
+            used[bj] = True
+            n += 1
+            box_err = max(box_err, float(np.abs(row[:4] - g[bj][:4]).max()))
+            sc_err = max(sc_err, float(abs(row[4] - g[bj][4])))
+    return len(r), len(g), n, box_err, sc_err
