@@ -1,0 +1,91 @@
+"""ctypes binding of libclearcam_hip.so (include/clearcam_hip.h).  Fails loudly when the library is absent."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclearcam_hip.so")
+
+# every symbol include/clearcam_hip.h declares
+SYMBOLS = [
+    "cc_last_error", "cc_version", "cc_device_count",
+    "cc_yolo_create", "cc_yolo_load", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_get_tensor",
+    "cc_yolo_last_gpu_ms", "cc_yolo_destroy", "cc_conv2d_nhwc",
+    "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
+    "cc_clip_last_gpu_ms", "cc_clip_destroy",
+    "cc_index_create", "cc_index_add", "cc_index_size", "cc_index_scores", "cc_index_search", "cc_index_destroy",
+]
+
+
+class ClipConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("image_size", "patch", "v_width", "v_layers", "v_heads", "v_mlp",
+                                       "t_ctx", "t_vocab", "t_width", "t_layers", "t_heads", "t_mlp", "embed")]
+
+
+class CCError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (no CPU fallback: a missing .so is an error, not a slow path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CCError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.cc_last_error.restype = C.c_char_p
+    vp, ip, fp, i64p = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int64)
+    sig = {
+        "cc_version": [],
+        "cc_device_count": [ip],
+        "cc_yolo_create": [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int],
+        "cc_yolo_load": [vp, C.c_char_p, vp, i64p, C.c_int],
+        "cc_yolo_finalize": [vp],
+        "cc_yolo_detect": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
+        "cc_yolo_get_tensor": [vp, C.c_char_p, vp, i64p, ip],
+        "cc_yolo_last_gpu_ms": [vp, fp],
+        "cc_conv2d_nhwc": [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                           C.c_int, vp, C.c_int, vp],
+        "cc_clip_create": [C.POINTER(vp), C.POINTER(ClipConfig), C.c_int, C.c_int],
+        "cc_clip_load": [vp, C.c_char_p, vp, i64p, C.c_int],
+        "cc_clip_finalize": [vp],
+        "cc_clip_encode_image": [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp],
+        "cc_clip_encode_text": [vp, vp, C.c_int, vp, C.c_int, vp],
+        "cc_clip_last_gpu_ms": [vp, fp],
+        "cc_index_create": [C.POINTER(vp), C.c_int, C.c_int64, C.c_int],
+        "cc_index_add": [vp, vp, C.c_int64, C.c_int],
+        "cc_index_size": [vp, i64p],
+        "cc_index_scores": [vp, vp, C.c_int, vp, C.c_int, vp],
+        "cc_index_search": [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name in ("cc_yolo_destroy", "cc_clip_destroy", "cc_index_destroy"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = None
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise CCError(f"libclearcam_hip error {rc}: {lib().cc_last_error().decode(errors='replace')}")
+
+
+def ptr(x):
+    """Raw address of a numpy array / torch tensor / int."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(x.ctypes.data)

@@ -1,0 +1,87 @@
+// Shared host/device helpers for libclearcam_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <stdexcept>
+
+namespace cc {
+
+enum DType : int { F32 = 0, F16 = 1, BF16 = 2 };
+
+inline size_t dtype_size(int dt) { return dt == F32 ? 4 : 2; }
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const std::string& msg);          // api.cpp (thread-local)
+struct Error : std::runtime_error { int code; Error(int c, const std::string& m) : std::runtime_error(m), code(c) {} };
+
+#define CC_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      throw cc::Error(-5, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+#define CC_CHECK(cond, msg)                                                                       \
+  do {                                                                                            \
+    if (!(cond)) throw cc::Error(-22, std::string(msg) + " [" #cond "] @" + __FILE__ + ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+// ---- 16-bit storage types -------------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+typedef _Float16 f16_t;
+
+template <class T> struct TypeTag;
+template <> struct TypeTag<float>  { static constexpr int dt = F32; };
+template <> struct TypeTag<f16_t>  { static constexpr int dt = F16; };
+template <> struct TypeTag<bf16_t> { static constexpr int dt = BF16; };
+
+__host__ __device__ inline float bf16_bits_to_f32(uint16_t b) {
+  union { uint32_t u; float f; } x; x.u = (uint32_t)b << 16; return x.f;
+}
+__host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {   // round-to-nearest-even
+  union { uint32_t u; float f; } x; x.f = f;
+  uint32_t u = x.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <class T> __host__ __device__ inline float to_f32(T v);
+template <> __host__ __device__ inline float to_f32<float>(float v) { return v; }
+template <> __host__ __device__ inline float to_f32<f16_t>(f16_t v) { return (float)v; }
+template <> __host__ __device__ inline float to_f32<bf16_t>(bf16_t v) { return bf16_bits_to_f32(v.v); }
+
+template <class T> __host__ __device__ inline T from_f32(float f);
+template <> __host__ __device__ inline float from_f32<float>(float f) { return f; }
+template <> __host__ __device__ inline f16_t from_f32<f16_t>(float f) { return (f16_t)f; }
+template <> __host__ __device__ inline bf16_t from_f32<bf16_t>(float f) { bf16_t r; r.v = f32_to_bf16_bits(f); return r; }
+
+// host-side conversion of an f32 array into the storage dtype
+void convert_f32_to(int dt, const float* src, void* dst, size_t n);
+
+// ---- tensor views (NHWC activations with channel stride) --------------------------------------
+// A Src is one channel range of a conv's input: a channel slice [coff, coff+C) of an NHWC buffer whose
+// pixels hold `cstride` channels.  shift=1 reads the buffer as if nearest-upsampled x2 (Upsample,
+// detection/yolov9.py:285-292 folded into the consumer's loader).
+struct Src {
+  const void* ptr; int H, W; int cstride, coff, C; int shift;
+};
+
+// One convolution / linear layer = implicit GEMM  out[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) (+res)
+//   m = (b, ho, wo) output pixel, n = output channel, k = (tap r,s ; channel c) with c over s0 then s1.
+struct ConvP {
+  Src s0, s1;
+  int B, Hin, Win, Cin;          // logical input dims (after shift), Cin = s0.C + s1.C
+  int Ho, Wo, Cout;
+  int ks, stride, pad;
+  int Ktot;                      // ks*ks*Cin
+  const void* w;                 // [Cout][Ktot], storage dtype
+  const float* bias;             // [Cout] or null
+  void* out; int out_cstride, out_coff; int out_f32;
+  const void* res; int res_cstride, res_coff; int res_f32;   // optional residual (same pixel grid as out)
+  int act;                       // 0 none, 1 SiLU, 2 tanh-GELU
+};
+
+}  // namespace cc

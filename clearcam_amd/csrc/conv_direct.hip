@@ -1,0 +1,98 @@
+// Generic direct convolution (one thread per output element) and pooling kernels.
+//
+// conv_direct is the correctness fallback for shapes the MFMA kernel rejects (channel counts that are
+// not multiples of 16 bytes: YOLOv9-m's 60/90/184-wide layers).  Same ConvP contract as conv_mfma.
+// Pools: avg_pool2d(k2,s1,p0) and max_pool2d(k3 s2 p1 / k5 s1 p2, -inf padding) of ADown/AConv/SPPELAN
+// (detection/yolov9.py:45-63,127-149), reading/writing channel slices of NHWC buffers.
+#include "kernels.h"
+
+namespace cc {
+
+template <class T>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvP p) {
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * p.Cout;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int n = (int)(idx % p.Cout);
+  const size_t m = idx / p.Cout;
+  const int hw = p.Ho * p.Wo;
+  const int b = (int)(m / hw), rem = (int)(m - (size_t)b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
+  const T* w = reinterpret_cast<const T*>(p.w) + (size_t)n * p.Ktot;
+  float acc = 0.f;
+  for (int r = 0; r < p.ks; ++r) {
+    const int ih = ho * p.stride - p.pad + r;
+    if ((unsigned)ih >= (unsigned)p.Hin) continue;
+    for (int s = 0; s < p.ks; ++s) {
+      const int iw = wo * p.stride - p.pad + s;
+      if ((unsigned)iw >= (unsigned)p.Win) continue;
+      const T* wk = w + (r * p.ks + s) * p.Cin;
+      {
+        const Src& S = p.s0;
+        const T* x = reinterpret_cast<const T*>(S.ptr) + ((size_t)(b * S.H + (ih >> S.shift)) * S.W + (iw >> S.shift)) * S.cstride + S.coff;
+        for (int c = 0; c < S.C; ++c) acc = fmaf(to_f32<T>(x[c]), to_f32<T>(wk[c]), acc);
+      }
+      if (p.s1.C > 0) {
+        const Src& S = p.s1;
+        const T* x = reinterpret_cast<const T*>(S.ptr) + ((size_t)(b * S.H + (ih >> S.shift)) * S.W + (iw >> S.shift)) * S.cstride + S.coff;
+        const T* wk1 = wk + p.s0.C;
+        for (int c = 0; c < S.C; ++c) acc = fmaf(to_f32<T>(x[c]), to_f32<T>(wk1[c]), acc);
+      }
+    }
+  }
+  float t = acc + (p.bias ? p.bias[n] : 0.f);
+  if (p.act == 1) t = t / (1.0f + expf(-t));
+  else if (p.act == 2) t = 0.5f * t * (1.0f + tanhf(0.7978845608028654f * (t + 0.044715f * t * t * t)));
+  if (p.res) {
+    const size_t ri = m * p.res_cstride + p.res_coff + n;
+    t = (p.res_f32 ? reinterpret_cast<const float*>(p.res)[ri] : to_f32<T>(reinterpret_cast<const T*>(p.res)[ri])) + t;
+  }
+  const size_t oi = m * p.out_cstride + p.out_coff + n;
+  if (p.out_f32) reinterpret_cast<float*>(p.out)[oi] = t;
+  else reinterpret_cast<T*>(p.out)[oi] = from_f32<T>(t);
+}
+
+void launch_conv_direct(int dt, const ConvP& p, hipStream_t stream) {
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * p.Cout;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dt == F32) hipLaunchKernelGGL(conv_direct_kernel<float>, grid, block, 0, stream, p);
+  else if (dt == F16) hipLaunchKernelGGL(conv_direct_kernel<f16_t>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(conv_direct_kernel<bf16_t>, grid, block, 0, stream, p);
+  CC_HIP(hipGetLastError());
+}
+
+// ---- pooling: one thread per (pixel, channel), channel fastest -----------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void pool_kernel(const PoolP p) {
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * p.C;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % p.C);
+  const size_t m = idx / p.C;
+  const int hw = p.Ho * p.Wo;
+  const int b = (int)(m / hw), rem = (int)(m - (size_t)b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
+  const T* in = reinterpret_cast<const T*>(p.in);
+  float acc = p.mode ? -INFINITY : 0.f;
+  for (int r = 0; r < p.k; ++r) {
+    const int ih = ho * p.stride - p.pad + r;
+    if ((unsigned)ih >= (unsigned)p.H) continue;
+    for (int s = 0; s < p.k; ++s) {
+      const int iw = wo * p.stride - p.pad + s;
+      if ((unsigned)iw >= (unsigned)p.W) continue;
+      const float v = to_f32<T>(in[((size_t)(b * p.H + ih) * p.W + iw) * p.in_cstride + p.in_coff + c]);
+      acc = p.mode ? fmaxf(acc, v) : acc + v;
+    }
+  }
+  if (!p.mode) acc = acc / (float)(p.k * p.k);
+  reinterpret_cast<T*>(p.out)[m * p.out_cstride + p.out_coff + c] = from_f32<T>(acc);
+}
+
+void launch_pool(int dt, const PoolP& p, hipStream_t stream) {
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * p.C;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dt == F32) hipLaunchKernelGGL(pool_kernel<float>, grid, block, 0, stream, p);
+  else if (dt == F16) hipLaunchKernelGGL(pool_kernel<f16_t>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(pool_kernel<bf16_t>, grid, block, 0, stream, p);
+  CC_HIP(hipGetLastError());
+}
+
+}  // namespace cc

@@ -1,0 +1,599 @@
+// Detector runtime: YOLOv9 t/s/m/c graph -> flat kernel list -> hipGraph, behind the C ABI.
+//
+// Stands behind YOLOv9.__init__/__call__ (detection/yolov9.py:298-388) and jit_infer's
+// shape-keyed cache (utils/helpers.py:214-221): one Plan (buffers + launch list + captured
+// hipGraph) per (B,H,W,frame dtype), replayed on later calls.
+//
+// MI355X-first choices (vs. the reference's op-by-op tensor graph):
+//   * NHWC activations; every Concat/chunk (yolov9.py:52,78,104,124,148,155) is a channel-offset
+//     view: producers write straight into the consumer's concat buffer, or the consumer conv reads
+//     two sources.  Upsample (:285-292) is folded into the consumer's loader (index>>1).
+//   * RepNCSP's two 1x1 convs over the same input (:101,103) and the head's two 3x3 convs over the
+//     same feature map (:205-206) are fused into one GEMM each (weights concatenated along Cout).
+//   * RepNBottleneck's residual (:89) is the conv epilogue, written in place.
+//   * grouped head convs (:172-181, K=144/16 per group) are densified to block-diagonal weights.
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include "kernels.h"
+#include "../../include/clearcam_hip.h"
+
+namespace cc {
+
+struct Arch {
+  const char* size; int stem; bool elan1; int b2_hidden, b2_out; bool adown; int d3_out, e4_hidden, p3, b4_out,
+      d5_out, e6_hidden, p4, d7_out, e8_hidden, p5, spp_hidden, d16_out, d19_out, cls_hidden, rep_n;
+};
+// detection/yolov9.py:461-464 (SIZES) by role; same table as clearcam_amd/arch.py.
+static const Arch kArch[] = {
+    {"t", 16, true, 32, 32, false, 64, 16, 64, 64, 96, 24, 96, 128, 32, 128, 64, 48, 64, 80, 3},
+    {"s", 32, true, 64, 64, false, 128, 32, 128, 128, 192, 48, 192, 256, 64, 256, 128, 96, 128, 128, 3},
+    {"m", 32, false, 32, 128, false, 240, 60, 240, 240, 360, 90, 360, 480, 120, 480, 240, 184, 240, 240, 1},
+    {"c", 64, false, 32, 256, true, 256, 64, 256, 512, 512, 128, 512, 512, 128, 512, 256, 256, 512, 256, 1},
+};
+
+struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
+struct PackedConv { void* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 0; };
+
+struct Buf { int H, W, C; bool f32; size_t off; };
+struct View { int buf; int coff; int C; };
+struct In { View v; int shift; };
+
+struct Op {
+  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms
+  ConvP conv; PoolP pool; DecodeP dec; NmsP nms;
+};
+
+struct Plan {
+  int B, H, W, frame_f32;
+  int nh, nw, pad_y, pad_x, Hn, Wn, A;
+  std::vector<Buf> bufs;
+  size_t arena_bytes = 0;
+  char* arena = nullptr;
+  std::vector<Op> ops;
+  std::map<std::string, int> taps;
+  int in_buf = -1;
+  int *xlo = nullptr, *xhi = nullptr, *ylo = nullptr, *yhi = nullptr; float *xfr = nullptr, *yfr = nullptr;
+  void* frames_dev = nullptr; size_t frames_bytes = 0;
+  float* det = nullptr; float* out_dev = nullptr;
+  hipGraphExec_t exec = nullptr;
+  ~Plan() {
+    if (exec) hipGraphExecDestroy(exec);
+    for (void* p : {(void*)arena, (void*)xlo, (void*)xhi, (void*)ylo, (void*)yhi, (void*)xfr, (void*)yfr, frames_dev, (void*)det, (void*)out_dev})
+      if (p) hipFree(p);
+  }
+};
+
+}  // namespace cc
+
+using namespace cc;
+
+struct cc_yolo {
+  const Arch* arch = nullptr;
+  int res = 640, dtype = BF16, device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::map<std::string, HostTensor> host;
+  std::map<std::string, PackedConv> packed;
+  float* dfl_w = nullptr;
+  bool finalized = false;
+  std::map<std::vector<int>, std::unique_ptr<Plan>> plans;
+  Plan* last = nullptr;
+  int cin_pad() const { return dtype == F32 ? 4 : 8; }
+};
+
+namespace cc {
+
+void convert_f32_to(int dt, const float* src, void* dst, size_t n) {
+  if (dt == F32) memcpy(dst, src, n * 4);
+  else if (dt == F16) { f16_t* d = (f16_t*)dst; for (size_t i = 0; i < n; ++i) d[i] = (f16_t)src[i]; }
+  else { uint16_t* d = (uint16_t*)dst; for (size_t i = 0; i < n; ++i) d[i] = f32_to_bf16_bits(src[i]); }
+}
+
+// Pack a list of OIHW convs over the same input into one [sum Cout][k*k*cin_pad] matrix (+ bias).
+// groups>1 convs become block-diagonal.  cin_pad >= cin zero-pads the channel axis (stem).
+static PackedConv pack_convs(int dt, const std::vector<const HostTensor*>& ws, const std::vector<const HostTensor*>& bs,
+                             const std::vector<int>& groups, int cin_pad) {
+  PackedConv pc;
+  const int k = (int)ws[0]->shape[2];
+  int cin = 0, cout = 0;
+  for (size_t t = 0; t < ws.size(); ++t) {
+    CC_CHECK(ws[t]->shape.size() == 4 && ws[t]->shape[2] == k && ws[t]->shape[3] == k, "conv weight must be OIHW");
+    const int ci = (int)ws[t]->shape[1] * groups[t];
+    CC_CHECK(cin == 0 || cin == ci, "fused convs must share Cin");
+    cin = ci; cout += (int)ws[t]->shape[0];
+  }
+  const int cp = cin_pad > cin ? cin_pad : cin;
+  const size_t ktot = (size_t)k * k * cp;
+  std::vector<float> w((size_t)cout * ktot, 0.f), bias(cout, 0.f);
+  int n0 = 0;
+  for (size_t t = 0; t < ws.size(); ++t) {
+    const int co = (int)ws[t]->shape[0], cig = (int)ws[t]->shape[1], g = groups[t], cog = co / g;
+    for (int n = 0; n < co; ++n) {
+      const int grp = n / cog;
+      for (int c = 0; c < cig; ++c)
+        for (int r = 0; r < k; ++r)
+          for (int s = 0; s < k; ++s)
+            w[(size_t)(n0 + n) * ktot + (size_t)(r * k + s) * cp + grp * cig + c] = ws[t]->data[(((size_t)n * cig + c) * k + r) * k + s];
+      if (bs[t]) bias[n0 + n] = bs[t]->data[n];
+    }
+    n0 += co;
+  }
+  std::vector<char> tmp(w.size() * dtype_size(dt));
+  convert_f32_to(dt, w.data(), tmp.data(), w.size());
+  CC_HIP(hipMalloc(&pc.w, tmp.size()));
+  CC_HIP(hipMemcpy(pc.w, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+  CC_HIP(hipMalloc((void**)&pc.bias, cout * 4));
+  CC_HIP(hipMemcpy(pc.bias, bias.data(), cout * 4, hipMemcpyHostToDevice));
+  pc.cin = cp; pc.cout = cout; pc.k = k;
+  return pc;
+}
+
+struct Builder {
+  cc_yolo* Y; Plan* P; const Arch& a;
+  Builder(cc_yolo* y, Plan* p) : Y(y), P(p), a(*y->arch) {}
+
+  int new_buf(int H, int W, int C, bool f32 = false) {
+    Buf b{H, W, C, f32, P->arena_bytes};
+    size_t bytes = (size_t)P->B * H * W * C * (f32 ? 4 : dtype_size(Y->dtype));
+    P->arena_bytes += (bytes + 255) & ~(size_t)255;
+    P->bufs.push_back(b);
+    return (int)P->bufs.size() - 1;
+  }
+  View whole(int buf) { return View{buf, 0, P->bufs[buf].C}; }
+  static View slice(View v, int c0, int C) { return View{v.buf, v.coff + c0, C}; }
+
+  const PackedConv& pconv(const std::vector<std::string>& names, const std::vector<int>& groups, int cin_pad = 0) {
+    std::string key;
+    for (auto& n : names) key += n + "+";
+    auto it = Y->packed.find(key);
+    if (it != Y->packed.end()) return it->second;
+    std::vector<const HostTensor*> ws, bs;
+    for (auto& n : names) {
+      auto w = Y->host.find(n + ".weight");
+      CC_CHECK(w != Y->host.end(), "missing parameter " + n + ".weight");
+      auto b = Y->host.find(n + ".bias");
+      CC_CHECK(b != Y->host.end(), "missing parameter " + n + ".bias");
+      ws.push_back(&w->second); bs.push_back(&b->second);
+    }
+    return Y->packed[key] = pack_convs(Y->dtype, ws, bs, groups, cin_pad);
+  }
+
+  Src src(const In& in) {
+    const Buf& b = P->bufs[in.v.buf];
+    return Src{nullptr, b.H, b.W, b.C, in.v.coff, in.v.C, in.shift};   // ptr patched after arena alloc
+  }
+
+  // conv op; pointers hold buffer ids until resolve()
+  void conv(const std::vector<In>& ins, const PackedConv& pc, View out, int stride, int act, const View* res = nullptr) {
+    Op op{}; op.kind = 0; ConvP& c = op.conv;
+    c.s0 = src(ins[0]); c.s0.ptr = (const void*)(intptr_t)ins[0].v.buf;
+    if (ins.size() > 1) { c.s1 = src(ins[1]); c.s1.ptr = (const void*)(intptr_t)ins[1].v.buf; }
+    else { c.s1 = Src{nullptr, 1, 1, 0, 0, 0, 0}; c.s1.ptr = (const void*)(intptr_t)-1; }
+    const Buf& b0 = P->bufs[ins[0].v.buf];
+    c.B = P->B; c.Hin = b0.H << ins[0].shift; c.Win = b0.W << ins[0].shift;
+    c.Cin = c.s0.C + c.s1.C;
+    CC_CHECK(c.Cin == pc.cin, "conv input channels do not match weights");
+    if (ins.size() > 1) {
+      const Buf& b1 = P->bufs[ins[1].v.buf];
+      CC_CHECK((b1.H << ins[1].shift) == c.Hin && (b1.W << ins[1].shift) == c.Win, "concat sources differ in size");
+    }
+    c.ks = pc.k; c.stride = stride; c.pad = pc.k / 2;
+    c.Ho = (c.Hin + 2 * c.pad - c.ks) / stride + 1; c.Wo = (c.Win + 2 * c.pad - c.ks) / stride + 1;
+    const Buf& ob = P->bufs[out.buf];
+    CC_CHECK(ob.H == c.Ho && ob.W == c.Wo && out.C == pc.cout, "conv output view mismatch");
+    c.Cout = pc.cout; c.Ktot = c.ks * c.ks * c.Cin;
+    c.w = pc.w; c.bias = pc.bias;
+    c.out = (void*)(intptr_t)out.buf; c.out_cstride = ob.C; c.out_coff = out.coff; c.out_f32 = ob.f32;
+    if (res) { const Buf& rb = P->bufs[res->buf]; c.res = (const void*)(intptr_t)res->buf; c.res_cstride = rb.C; c.res_coff = res->coff; c.res_f32 = rb.f32; }
+    else { c.res = (const void*)(intptr_t)-1; }
+    c.act = act;
+    P->ops.push_back(op);
+  }
+
+  void pool(View in, View out, int k, int stride, int pad, int mode) {
+    Op op{}; op.kind = 1; PoolP& q = op.pool;
+    const Buf& ib = P->bufs[in.buf]; const Buf& ob = P->bufs[out.buf];
+    q.in = (const void*)(intptr_t)in.buf; q.in_cstride = ib.C; q.in_coff = in.coff;
+    q.out = (void*)(intptr_t)out.buf; q.out_cstride = ob.C; q.out_coff = out.coff;
+    q.B = P->B; q.H = ib.H; q.W = ib.W; q.C = in.C; q.Ho = ob.H; q.Wo = ob.W; q.k = k; q.stride = stride; q.pad = pad; q.mode = mode;
+    CC_CHECK(in.C == out.C && ob.H == (ib.H + 2 * pad - k) / stride + 1 && ob.W == (ib.W + 2 * pad - k) / stride + 1, "pool view mismatch");
+    P->ops.push_back(op);
+  }
+
+  // ---- blocks (detection/yolov9.py:40-149) ---------------------------------------------------
+  int dimH(const In& in) { return P->bufs[in.v.buf].H << in.shift; }
+  int dimW(const In& in) { return P->bufs[in.v.buf].W << in.shift; }
+
+  // RepNCSP (:92-105) + trailing 3x3 Conv (:112,115): in -> out
+  void csp_branch(const std::string& p, View in, View out, int hid) {
+    const int H = P->bufs[in.buf].H, W = P->bufs[in.buf].W;
+    const int csp = new_buf(H, W, 2 * hid), t = new_buf(H, W, hid), u = new_buf(H, W, 2 * hid);
+    const std::string r = p + ".list.0";
+    conv({{in, 0}}, pconv({r + ".cv1.conv", r + ".cv2.conv"}, {1, 1}), whole(csp), 1, 1);
+    const View x1 = slice(whole(csp), 0, hid);
+    for (int j = 0; j < a.rep_n; ++j) {
+      const std::string q = r + ".m.list." + std::to_string(j);
+      conv({{x1, 0}}, pconv({q + ".cv1.conv"}, {1}), whole(t), 1, 1);
+      conv({{whole(t), 0}}, pconv({q + ".cv2.conv"}, {1}), x1, 1, 1, &x1);   // x + cv2(cv1(x)), in place
+    }
+    conv({{whole(csp), 0}}, pconv({r + ".cv3.conv"}, {1}), whole(u), 1, 1);
+    conv({{whole(u), 0}}, pconv({p + ".list.1.conv"}, {1}), out, 1, 1);
+  }
+
+  View elan4(const std::string& p, const std::vector<In>& ins, int hid, int cout) {   // RepNCSPELAN4 :107-125
+    const int H = dimH(ins[0]), W = dimW(ins[0]);
+    const int cat = new_buf(H, W, 8 * hid), o = new_buf(H, W, cout);
+    conv(ins, pconv({p + ".cv1.conv"}, {1}), slice(whole(cat), 0, 4 * hid), 1, 1);
+    csp_branch(p + ".cv2", slice(whole(cat), 2 * hid, 2 * hid), slice(whole(cat), 4 * hid, 2 * hid), hid);
+    csp_branch(p + ".cv3", slice(whole(cat), 4 * hid, 2 * hid), slice(whole(cat), 6 * hid, 2 * hid), hid);
+    conv({{whole(cat), 0}}, pconv({p + ".cv4.conv"}, {1}), whole(o), 1, 1);
+    return whole(o);
+  }
+
+  View elan1(const std::string& p, View in, int hid, int cout) {   // ELAN1 :65-80
+    const int H = P->bufs[in.buf].H, W = P->bufs[in.buf].W;
+    const int cat = new_buf(H, W, 2 * hid), o = new_buf(H, W, cout);
+    conv({{in, 0}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(cat), 0, hid), 1, 1);
+    conv({{slice(whole(cat), hid / 2, hid / 2), 0}}, pconv({p + ".cv2.conv"}, {1}), slice(whole(cat), hid, hid / 2), 1, 1);
+    conv({{slice(whole(cat), hid, hid / 2), 0}}, pconv({p + ".cv3.conv"}, {1}), slice(whole(cat), hid + hid / 2, hid / 2), 1, 1);
+    conv({{whole(cat), 0}}, pconv({p + ".cv4.conv"}, {1}), whole(o), 1, 1);
+    return whole(o);
+  }
+
+  View down(const std::string& p, View in, int cout) {   // ADown :40-52 / AConv :54-63
+    const int H = P->bufs[in.buf].H, W = P->bufs[in.buf].W, C = in.C;
+    const int avg = new_buf(H - 1, W - 1, C);
+    pool(in, whole(avg), 2, 1, 0, 0);
+    const int Ho = (H - 1 + 2 - 3) / 2 + 1, Wo = (W - 1 + 2 - 3) / 2 + 1;
+    const int o = new_buf(Ho, Wo, cout);
+    if (a.adown) {
+      CC_CHECK(C == cout, "ADown keeps the channel count");
+      conv({{slice(whole(avg), 0, C / 2), 0}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(o), 0, C / 2), 2, 1);
+      const int mp = new_buf(Ho, Wo, C / 2);
+      pool(slice(whole(avg), C / 2, C / 2), whole(mp), 3, 2, 1, 1);
+      conv({{whole(mp), 0}}, pconv({p + ".cv2.conv"}, {1}), slice(whole(o), C / 2, C / 2), 1, 1);
+    } else {
+      conv({{whole(avg), 0}}, pconv({p + ".cv1.conv"}, {1}), whole(o), 2, 1);
+    }
+    return whole(o);
+  }
+
+  View sppelan(const std::string& p, View in, int hid, int cout) {   // SPPELAN :127-149
+    const int H = P->bufs[in.buf].H, W = P->bufs[in.buf].W;
+    const int cat = new_buf(H, W, 4 * hid), o = new_buf(H, W, cout);
+    conv({{in, 0}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(cat), 0, hid), 1, 1);
+    for (int i = 0; i < 3; ++i) pool(slice(whole(cat), i * hid, hid), slice(whole(cat), (i + 1) * hid, hid), 5, 1, 2, 1);
+    conv({{whole(cat), 0}}, pconv({p + ".cv5.conv"}, {1}), whole(o), 1, 1);
+    return whole(o);
+  }
+
+  void build() {
+    const std::string M = "model.list.";
+    const int cp = Y->cin_pad();
+    P->in_buf = new_buf(P->Hn, P->Wn, cp);
+    P->taps["input"] = P->in_buf;
+    const int b0 = new_buf(P->Hn / 2, P->Wn / 2, a.stem);
+    conv({{whole(P->in_buf), 0}}, pconv({M + "0.conv"}, {1}, cp), whole(b0), 2, 1);
+    const int b1 = new_buf(P->Hn / 4, P->Wn / 4, 2 * a.stem);
+    conv({{whole(b0), 0}}, pconv({M + "1.conv"}, {1}), whole(b1), 2, 1);
+    const View y2 = a.elan1 ? elan1(M + "2", whole(b1), a.b2_hidden, a.b2_out) : elan4(M + "2", {{whole(b1), 0}}, a.b2_hidden, a.b2_out);
+    const View y3 = down(M + "3", y2, a.d3_out);
+    const View y4 = elan4(M + "4", {{y3, 0}}, a.e4_hidden, a.b4_out);
+    const View y5 = down(M + "5", y4, a.d5_out);
+    const View y6 = elan4(M + "6", {{y5, 0}}, a.e6_hidden, a.p4);
+    const View y7 = down(M + "7", y6, a.d7_out);
+    const View y8 = elan4(M + "8", {{y7, 0}}, a.e8_hidden, a.p5);
+    const View y9 = sppelan(M + "9", y8, a.spp_hidden, a.p5);
+    const View y12 = elan4(M + "12", {{y9, 1}, {y6, 0}}, a.e6_hidden, a.p4);
+    const View y15 = elan4(M + "15", {{y12, 1}, {y4, 0}}, a.e4_hidden, a.p3);
+    const View y16 = down(M + "16", y15, a.d16_out);
+    const View y18 = elan4(M + "18", {{y16, 0}, {y12, 0}}, a.e6_hidden, a.p4);
+    const View y19 = down(M + "19", y18, a.d19_out);
+    const View y21 = elan4(M + "21", {{y19, 0}, {y9, 0}}, a.e8_hidden, a.p5);
+    P->taps["p3"] = y15.buf; P->taps["p4"] = y18.buf; P->taps["p5"] = y21.buf;
+
+    // DDetect (:157-220)
+    const View feats[3] = {y15, y18, y21};
+    Op dec{}; dec.kind = 2;
+    P->A = 0;
+    for (int l = 0; l < 3; ++l) {
+      const std::string hb = M + "22.cv2.list." + std::to_string(l) + ".list.", hc = M + "22.cv3.list." + std::to_string(l) + ".list.";
+      const int H = P->bufs[feats[l].buf].H, W = P->bufs[feats[l].buf].W, ch = a.cls_hidden;
+      const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch), raw = new_buf(H, W, 144, true);
+      conv({{feats[l], 0}}, pconv({hb + "0.conv", hc + "0.conv"}, {1, 1}), whole(hbuf), 1, 1);
+      conv({{slice(whole(hbuf), 0, 64), 0}}, pconv({hb + "1.conv"}, {4}), whole(bxb), 1, 1);
+      conv({{slice(whole(hbuf), 64, ch), 0}}, pconv({hc + "1.conv"}, {1}), whole(clb), 1, 1);
+      conv({{whole(bxb), 0}}, pconv({hb + "2"}, {4}), slice(whole(raw), 0, 64), 1, 0);
+      conv({{whole(clb), 0}}, pconv({hc + "2"}, {1}), slice(whole(raw), 64, 80), 1, 0);
+      P->taps["raw" + std::to_string(l)] = raw;
+      dec.dec.raw[l] = (const float*)(intptr_t)raw; dec.dec.H[l] = H; dec.dec.W[l] = W;
+      P->A += H * W;
+    }
+    dec.dec.B = P->B; dec.dec.A = P->A; dec.dec.dfl_w = Y->dfl_w; dec.dec.conf = 0.25f;
+    P->ops.push_back(dec);
+    Op nms{}; nms.kind = 3;
+    nms.nms.B = P->B; nms.nms.A = P->A; nms.nms.iou_thr = 0.45f;
+    // scale_boxes (:406-416): python-float arithmetic, then f32 tensor ops
+    const double gain = std::min((double)P->Hn / P->H, (double)P->Wn / P->W);
+    nms.nms.gain = (float)gain;
+    nms.nms.pad_x = (float)((P->Wn - P->W * gain) / 2); nms.nms.pad_y = (float)((P->Hn - P->H * gain) / 2);
+    nms.nms.src_w = (float)P->W; nms.nms.src_h = (float)P->H;
+    P->ops.push_back(nms);
+  }
+
+  void resolve() {
+    CC_HIP(hipMalloc((void**)&P->arena, P->arena_bytes));
+    CC_HIP(hipMemset(P->arena, 0, P->arena_bytes));
+    CC_HIP(hipMalloc((void**)&P->det, (size_t)P->B * P->A * 6 * 4));
+    CC_HIP(hipMalloc((void**)&P->out_dev, (size_t)P->B * CC_MAX_DET * 6 * 4));
+    auto ptr = [&](const void* id) -> char* { const intptr_t i = (intptr_t)id; return i < 0 ? nullptr : P->arena + P->bufs[i].off; };
+    for (Op& op : P->ops) {
+      if (op.kind == 0) {
+        op.conv.s0.ptr = ptr(op.conv.s0.ptr); op.conv.s1.ptr = ptr(op.conv.s1.ptr);
+        if (!op.conv.s1.ptr) op.conv.s1.ptr = op.conv.s0.ptr;
+        op.conv.out = ptr(op.conv.out); op.conv.res = ptr(op.conv.res);
+      } else if (op.kind == 1) { op.pool.in = ptr(op.pool.in); op.pool.out = ptr(op.pool.out); }
+      else if (op.kind == 2) { for (int l = 0; l < 3; ++l) op.dec.raw[l] = (const float*)ptr(op.dec.raw[l]); op.dec.det = P->det; }
+      else { op.nms.det = P->det; op.nms.out = P->out_dev; }
+    }
+  }
+};
+
+// tinygrad interpolate index tables in float32; mirrors oracle interp_axis_tables.
+#pragma clang fp contract(off)
+static void axis_tables(int n_in, int n_out, std::vector<int>& lo, std::vector<int>& hi, std::vector<float>& fr) {
+  lo.resize(n_out); hi.resize(n_out); fr.resize(n_out);
+  const float scale = (float)((double)n_in / (double)n_out);
+  for (int i = 0; i < n_out; ++i) {
+    volatile float t = (float)i + 0.5f;
+    volatile float u = scale * t;
+    volatile float idx = u - 0.5f;
+    float v = idx;
+    if (v < 0.f) v = 0.f;
+    if (v > (float)(n_in - 1)) v = (float)(n_in - 1);
+    const float f = floorf(v);
+    lo[i] = (int)f; hi[i] = (int)ceilf(v);
+    volatile float d = v - f;
+    fr[i] = d;
+  }
+}
+
+static int round_half_even(double x) { return (int)std::nearbyint(x); }
+
+template <class T> static T* to_device(const std::vector<T>& v) {
+  T* d = nullptr;
+  CC_HIP(hipMalloc((void**)&d, v.size() * sizeof(T) + 16));
+  CC_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+static void run_ops(cc_yolo* Y, Plan* P, hipStream_t s) {
+  for (const Op& op : P->ops) {
+    if (op.kind == 0) launch_conv(Y->dtype, op.conv, s);
+    else if (op.kind == 1) launch_pool(Y->dtype, op.pool, s);
+    else if (op.kind == 2) launch_decode(op.dec, s);
+    else launch_topk_nms(op.nms, s);
+  }
+}
+
+static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32) {
+  const std::vector<int> key{B, H, W, frame_f32};
+  auto it = Y->plans.find(key);
+  if (it != Y->plans.end()) return it->second.get();
+  std::unique_ptr<Plan> P(new Plan());
+  P->B = B; P->H = H; P->W = W; P->frame_f32 = frame_f32;
+  // letterbox geometry, detection/yolov9.py:390-403 (python round = half-to-even)
+  const int res = Y->res;
+  const double r = std::min((double)res / H, (double)res / W);
+  P->nw = round_half_even(W * r); P->nh = round_half_even(H * r);
+  const double dw = ((res - P->nw) % 32) / 2.0, dh = ((res - P->nh) % 32) / 2.0;
+  P->pad_x = round_half_even(dw - 0.1); P->pad_y = round_half_even(dh - 0.1);
+  P->Hn = P->nh + 2 * P->pad_y; P->Wn = P->nw + 2 * P->pad_x;
+  CC_CHECK(P->Hn % 32 == 0 && P->Wn % 32 == 0 && P->Hn > 0 && P->Wn > 0,
+           "letterboxed frame is not a multiple of 32 (the reference graph cannot run this shape either)");
+  std::vector<int> lo, hi; std::vector<float> fr;
+  axis_tables(W, P->nw, lo, hi, fr); P->xlo = to_device(lo); P->xhi = to_device(hi); P->xfr = to_device(fr);
+  axis_tables(H, P->nh, lo, hi, fr); P->ylo = to_device(lo); P->yhi = to_device(hi); P->yfr = to_device(fr);
+  Builder bld(Y, P.get());
+  bld.build();
+  bld.resolve();
+  P->frames_bytes = (size_t)B * H * W * 3 * (frame_f32 ? 4 : 1);
+  CC_HIP(hipMalloc(&P->frames_dev, P->frames_bytes));
+  // capture the launch list once; replay afterwards (the TinyJit role, helpers.py:214-221)
+  hipGraph_t graph = nullptr;
+  CC_HIP(hipStreamBeginCapture(Y->stream, hipStreamCaptureModeThreadLocal));
+  try { run_ops(Y, P.get(), Y->stream); } catch (...) { hipStreamEndCapture(Y->stream, &graph); if (graph) hipGraphDestroy(graph); throw; }
+  CC_HIP(hipStreamEndCapture(Y->stream, &graph));
+  CC_HIP(hipGraphInstantiate(&P->exec, graph, nullptr, nullptr, 0));
+  CC_HIP(hipGraphDestroy(graph));
+  Plan* raw = P.get();
+  Y->plans[key] = std::move(P);
+  return raw;
+}
+
+}  // namespace cc
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+namespace cc { void set_error(const std::string& m) { g_err = m; } }
+
+#define CC_API_BEGIN try {
+#define CC_API_END                                                         \
+  return 0; }                                                              \
+  catch (const cc::Error& e) { cc::set_error(e.what()); return e.code; }   \
+  catch (const std::exception& e) { cc::set_error(e.what()); return -1; }
+
+extern "C" {
+
+const char* cc_last_error(void) { return g_err.c_str(); }
+int cc_version(void) { return 100; }
+int cc_device_count(int* n) { CC_API_BEGIN CC_HIP(hipGetDeviceCount(n)); CC_API_END }
+
+int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device) {
+  CC_API_BEGIN
+  CC_CHECK(h && size, "null argument");
+  CC_CHECK(dtype >= 0 && dtype <= 2, "dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+  CC_CHECK(res > 0 && res % 32 == 0, "res must be a positive multiple of 32");
+  const Arch* a = nullptr;
+  for (const Arch& x : kArch) if (!strcmp(x.size, size)) a = &x;
+  CC_CHECK(a, std::string("unknown model size '") + size + "' (t, s, m, c)");
+  int n = 0; CC_HIP(hipGetDeviceCount(&n));
+  CC_CHECK(n > 0 && device >= 0 && device < n, "no such HIP device");
+  CC_HIP(hipSetDevice(device));
+  std::unique_ptr<cc_yolo> y(new cc_yolo());
+  y->arch = a; y->res = res; y->dtype = dtype; y->device = device;
+  CC_HIP(hipStreamCreateWithFlags(&y->stream, hipStreamNonBlocking));
+  CC_HIP(hipEventCreate(&y->ev0)); CC_HIP(hipEventCreate(&y->ev1));
+  *h = y.release();
+  CC_API_END
+}
+
+int cc_yolo_load(cc_yolo* h, const char* name, const float* data, const int64_t* shape, int ndim) {
+  CC_API_BEGIN
+  CC_CHECK(h && name && data && shape && ndim >= 0 && ndim <= 4, "bad argument");
+  CC_CHECK(!h->finalized, "cc_yolo_load after cc_yolo_finalize");
+  HostTensor t; size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.assign(data, data + n);
+  h->host[name] = std::move(t);
+  CC_API_END
+}
+
+int cc_yolo_finalize(cc_yolo* h) {
+  CC_API_BEGIN
+  CC_CHECK(h, "null handle");
+  CC_HIP(hipSetDevice(h->device));
+  auto d = h->host.find("model.list.22.dfl.conv.weight");
+  CC_CHECK(d != h->host.end() && d->second.data.size() == 16, "missing parameter model.list.22.dfl.conv.weight");
+  CC_HIP(hipMalloc((void**)&h->dfl_w, 64));
+  CC_HIP(hipMemcpy(h->dfl_w, d->second.data.data(), 64, hipMemcpyHostToDevice));
+  // dry-run build at B=1, res x res: packs every conv and proves the parameter set is complete
+  Plan P; P.B = 1; P.H = P.W = P.Hn = P.Wn = h->res; P.nh = P.nw = h->res; P.pad_x = P.pad_y = 0;
+  Builder(h, &P).build();
+  h->finalized = true;
+  h->host.clear();
+  CC_API_END
+}
+
+int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int frame_f32, int frames_on_device,
+                   float* out, int out_on_device, void* stream) {
+  CC_API_BEGIN
+  CC_CHECK(h && frames && out, "null argument");
+  CC_CHECK(h->finalized, "cc_yolo_detect before cc_yolo_finalize");
+  CC_CHECK(B > 0 && H > 0 && W > 0, "bad frame shape");
+  CC_HIP(hipSetDevice(h->device));
+  Plan* P = get_plan(h, B, H, W, frame_f32 ? 1 : 0);
+  hipStream_t s = h->stream;
+  if (stream) {   // order our stream after the caller's
+    hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CC_HIP(hipEventRecord(e, (hipStream_t)stream)); CC_HIP(hipStreamWaitEvent(s, e, 0)); CC_HIP(hipEventDestroy(e));
+  }
+  const void* fdev = frames;
+  if (!frames_on_device) { CC_HIP(hipMemcpyAsync(P->frames_dev, frames, P->frames_bytes, hipMemcpyHostToDevice, s)); fdev = P->frames_dev; }
+  CC_HIP(hipEventRecord(h->ev0, s));
+  PreP pp{};
+  pp.frames = fdev; pp.frame_f32 = P->frame_f32; pp.B = B; pp.H = H; pp.W = W;
+  pp.nh = P->nh; pp.nw = P->nw; pp.pad_y = P->pad_y; pp.pad_x = P->pad_x; pp.Hn = P->Hn; pp.Wn = P->Wn;
+  pp.xlo = P->xlo; pp.xhi = P->xhi; pp.xfr = P->xfr; pp.ylo = P->ylo; pp.yhi = P->yhi; pp.yfr = P->yfr;
+  pp.out = P->arena + P->bufs[P->in_buf].off; pp.out_c = P->bufs[P->in_buf].C;
+  launch_preprocess(h->dtype, pp, s);
+  CC_HIP(hipGraphLaunch(P->exec, s));
+  CC_HIP(hipEventRecord(h->ev1, s));
+  const size_t ob = (size_t)B * CC_MAX_DET * 6 * 4;
+  if (out_on_device) {
+    CC_HIP(hipMemcpyAsync(out, P->out_dev, ob, hipMemcpyDeviceToDevice, s));
+    if (stream) {
+      hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      CC_HIP(hipEventRecord(e, s)); CC_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0)); CC_HIP(hipEventDestroy(e));
+    }
+  } else {
+    CC_HIP(hipMemcpyAsync(out, P->out_dev, ob, hipMemcpyDeviceToHost, s));
+    CC_HIP(hipStreamSynchronize(s));
+  }
+  h->last = P;
+  CC_API_END
+}
+
+int cc_yolo_get_tensor(cc_yolo* h, const char* name, float* out, int64_t* shape, int* ndim) {
+  CC_API_BEGIN
+  CC_CHECK(h && name && shape && ndim, "null argument");
+  CC_CHECK(h->last, "no detect call yet");
+  Plan* P = h->last;
+  CC_HIP(hipSetDevice(h->device));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  if (!strcmp(name, "decoded")) {
+    shape[0] = P->B; shape[1] = P->A; shape[2] = 6; *ndim = 3;
+    if (out) CC_HIP(hipMemcpy(out, P->det, (size_t)P->B * P->A * 24, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  auto it = P->taps.find(name);
+  CC_CHECK(it != P->taps.end(), std::string("unknown tensor '") + name + "'");
+  const Buf& b = P->bufs[it->second];
+  const int C = !strcmp(name, "input") ? 3 : b.C;
+  shape[0] = P->B; shape[1] = b.H; shape[2] = b.W; shape[3] = C; *ndim = 4;
+  if (!out) return 0;
+  const size_t n = (size_t)P->B * b.H * b.W * b.C;
+  const size_t es = b.f32 ? 4 : dtype_size(h->dtype);
+  std::vector<char> tmp(n * es);
+  CC_HIP(hipMemcpy(tmp.data(), P->arena + b.off, n * es, hipMemcpyDeviceToHost));
+  const size_t px = (size_t)P->B * b.H * b.W;
+  for (size_t i = 0; i < px; ++i)
+    for (int c = 0; c < C; ++c) {
+      const size_t j = i * b.C + c;
+      float v;
+      if (b.f32 || h->dtype == F32) v = ((const float*)tmp.data())[j];
+      else if (h->dtype == F16) v = (float)((const f16_t*)tmp.data())[j];
+      else v = bf16_bits_to_f32(((const uint16_t*)tmp.data())[j]);
+      out[i * C + c] = v;
+    }
+  CC_API_END
+}
+
+int cc_yolo_last_gpu_ms(cc_yolo* h, float* ms) {
+  CC_API_BEGIN
+  CC_CHECK(h && ms && h->last, "no detect call yet");
+  CC_HIP(hipEventSynchronize(h->ev1));
+  CC_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  CC_API_END
+}
+
+void cc_yolo_destroy(cc_yolo* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  h->plans.clear();
+  for (auto& kv : h->packed) { hipFree(kv.second.w); hipFree(kv.second.bias); }
+  if (h->dfl_w) hipFree(h->dfl_w);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, const float* w_oihw, const float* bias,
+                   int Cout, int k, int stride, int groups, int act, void* out_dev, int force_direct, void* stream) {
+  CC_API_BEGIN
+  CC_CHECK(x_dev && w_oihw && out_dev && groups >= 1 && Cin % groups == 0 && Cout % groups == 0, "bad argument");
+  HostTensor w, b;
+  w.shape = {Cout, Cin / groups, k, k};
+  w.data.assign(w_oihw, w_oihw + (size_t)Cout * (Cin / groups) * k * k);
+  if (bias) { b.shape = {Cout}; b.data.assign(bias, bias + Cout); }
+  PackedConv pc = pack_convs(dtype, {&w}, {bias ? &b : nullptr}, {groups}, 0);
+  ConvP c{};
+  c.s0 = Src{x_dev, H, W, Cin, 0, Cin, 0}; c.s1 = Src{x_dev, 1, 1, 0, 0, 0, 0};
+  c.B = B; c.Hin = H; c.Win = W; c.Cin = Cin; c.ks = k; c.stride = stride; c.pad = k / 2;
+  c.Ho = (H + 2 * c.pad - k) / stride + 1; c.Wo = (W + 2 * c.pad - k) / stride + 1; c.Cout = Cout; c.Ktot = k * k * Cin;
+  c.w = pc.w; c.bias = pc.bias; c.out = out_dev; c.out_cstride = Cout; c.out_coff = 0; c.out_f32 = 0; c.res = nullptr; c.act = act;
+  if (force_direct) launch_conv_direct(dtype, c, (hipStream_t)stream); else launch_conv(dtype, c, (hipStream_t)stream);
+  CC_HIP(hipStreamSynchronize((hipStream_t)stream));
+  hipFree(pc.w); hipFree(pc.bias);
+  CC_API_END
+}
+
+}  // extern "C"

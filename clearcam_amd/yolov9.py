@@ -1,0 +1,116 @@
+"""Host-side mirror of ``detection/yolov9.py``: same class name, constructor and call surface,
+compute in libclearcam_hip (HIP/MFMA) through the C ABI in include/clearcam_hip.h.
+
+    model = YOLOv9("c", 640, state_dict=sd)          # reference: YOLOv9(size, res) + download
+    preds = jit_infer(model, Tensor(frame), cache).numpy()     # (300,6) float32, clearcam.py:583
+
+There is no CPU path: without the HIP library / a GPU every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .arch import YOLO_ARCH
+from .helpers import Tensor, as_numpy
+from .weights import load_safetensors
+
+DTYPES = {"f32": 0, "float32": 0, "f16": 1, "float16": 1, "half": 1, "bf16": 2, "bfloat16": 2}
+MAX_DET = 300
+
+
+class YOLOv9:
+    def __init__(self, size: str = "t", res: int = 1280, state_dict: Optional[Dict[str, np.ndarray]] = None,
+                 weights: Optional[str] = None, dtype: str = "bf16", device: int = 0):
+        if size not in YOLO_ARCH:
+            raise ValueError(f"unsupported size {size!r}: t, s, m, c (size 'e' is not built yet)")
+        self.size, self.res, self.dtype, self.device = size, res, dtype, device
+        if state_dict is None:
+            # reference: safe_load(fetch(".../yolov9-{size}.safetensors")) (yolov9.py:372); no network here
+            path = weights or os.path.join(os.environ.get("CLEARCAM_WEIGHTS_DIR", "weights"), f"yolov9-{size}.safetensors")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{path} not found: pass state_dict= or weights= (the reference downloads "
+                                        f"yolov9-{size}.safetensors from HuggingFace; there is no network here)")
+            state_dict = load_safetensors(path)
+        L = _lib.lib()
+        self._h = C.c_void_p()
+        _lib.check(L.cc_yolo_create(C.byref(self._h), size.encode(), res, DTYPES[dtype], device))
+        for name, arr in state_dict.items():
+            if name.endswith(("anchors", "strides")):      # Tensor attributes the reference recomputes per call
+                continue
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shp = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            _lib.check(L.cc_yolo_load(self._h, name.encode(), _lib.ptr(a), shp, a.ndim))
+        _lib.check(L.cc_yolo_finalize(self._h))
+
+    # -- reference surface ------------------------------------------------------------------------
+    def __call__(self, frame) -> Tensor:
+        """``YOLOv9.__call__(frame)``: (H,W,3) BGR uint8/float32 -> Tensor (300,6)."""
+        f = as_numpy(frame)
+        if f.ndim != 3 or f.shape[2] != 3:
+            raise ValueError(f"frame must be (H,W,3), got {f.shape}")
+        return Tensor(self.detect_batch(f[None])[0])
+
+    # -- batched extension (one camera per row) ---------------------------------------------------
+    def detect_batch(self, frames) -> np.ndarray:
+        """(B,H,W,3) BGR uint8/float32 host array or CUDA torch tensor -> (B,300,6) float32 ndarray."""
+        L = _lib.lib()
+        on_dev = bool(getattr(frames, "is_cuda", False))
+        if on_dev:
+            import torch
+            f = frames.contiguous()
+            is_f32 = f.dtype == torch.float32
+            if not is_f32 and f.dtype != torch.uint8:
+                raise TypeError("device frames must be uint8 or float32")
+            B, H, W, ch = f.shape
+            torch.cuda.current_stream(f.device).synchronize()
+        else:
+            f = as_numpy(frames)
+            if f.dtype != np.uint8:
+                f = f.astype(np.float32, copy=False)
+            f = np.ascontiguousarray(f)
+            is_f32 = f.dtype == np.float32
+            B, H, W, ch = f.shape
+        if ch != 3:
+            raise ValueError("frames must be (B,H,W,3)")
+        out = np.empty((B, MAX_DET, 6), np.float32)
+        _lib.check(L.cc_yolo_detect(self._h, _lib.ptr(f), B, H, W, int(is_f32), int(on_dev), _lib.ptr(out), 0, None))
+        return out
+
+    def detect_batch_device(self, frames, out):
+        """Device-resident variant for benchmarks: frames/out are CUDA torch tensors; no host copies, no sync."""
+        import torch
+        B, H, W, _ = frames.shape
+        s = torch.cuda.current_stream(frames.device).cuda_stream
+        _lib.check(_lib.lib().cc_yolo_detect(self._h, _lib.ptr(frames), B, H, W, int(frames.dtype == torch.float32), 1,
+                                             _lib.ptr(out), 1, C.c_void_p(s)))
+        return out
+
+    # -- parity taps --------------------------------------------------------------------------------
+    def get_tensor(self, name: str) -> np.ndarray:
+        L = _lib.lib()
+        shp, nd = (C.c_int64 * 4)(), C.c_int()
+        _lib.check(L.cc_yolo_get_tensor(self._h, name.encode(), None, shp, C.byref(nd)))
+        out = np.empty(tuple(shp[i] for i in range(nd.value)), np.float32)
+        _lib.check(L.cc_yolo_get_tensor(self._h, name.encode(), _lib.ptr(out), shp, C.byref(nd)))
+        return out
+
+    def last_gpu_ms(self) -> float:
+        ms = C.c_float()
+        _lib.check(_lib.lib().cc_yolo_last_gpu_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().cc_yolo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

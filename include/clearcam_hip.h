@@ -1,0 +1,105 @@
+/* libclearcam_hip — C ABI of the MI355X-native detect / CLIP-encode / search path for clearcam.
+ *
+ * The reference (roryclear/clearcam) has no FFI for this path: its boundary is three duck-typed Python
+ * call surfaces that sit directly on tinygrad.  Each entry point below names the reference interface
+ * it stands behind; the Python shim in clearcam_amd/ keeps those surfaces byte-compatible and
+ * INTEGRATION.md shows the ctypes binding a clearcam maintainer would add.
+ *
+ * Conventions: every function returns 0 on success or a negative errno-style code, with a thread-local
+ * message available from cc_last_error().  The caller owns every buffer it passes.  A handle belongs to
+ * one GPU and one submitting thread at a time (the reference runs all tensor work on its main thread,
+ * clearcam.py:1214-1226).  `stream` is a hipStream_t (NULL = the handle's own stream); when results
+ * go to host memory the call returns after they have landed, otherwise it only enqueues work.
+ */
+#ifndef CLEARCAM_HIP_H
+#define CLEARCAM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CC_DTYPE_F32 0   /* parity mode: f32 storage, exact-f32 MFMA                  */
+#define CC_DTYPE_F16 1   /* speed mode:  f16 storage, f32 accumulate                  */
+#define CC_DTYPE_BF16 2  /* speed mode:  bf16 storage, f32 accumulate (bench default) */
+
+#define CC_MAX_DET 300   /* rows per frame of the detector output (detection/yolov9.py:439) */
+
+const char* cc_last_error(void);
+int cc_version(void);
+int cc_device_count(int* n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Detector — stands behind `YOLOv9(size, res)` and `YOLOv9.__call__(frame)`
+ * (detection/yolov9.py:298-388), as called from clearcam.py:583 and test/run_mot.py:34.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cc_yolo cc_yolo;
+
+/* YOLOv9.__init__ (yolov9.py:298-326): size in {"t","s","m","c"}, res = letterbox target. */
+int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device);
+/* load_state_dict (yolov9.py:372-373): one call per state-dict entry, reference key names
+ * (SURVEY.md Appendix C), host float32 data, OIHW weights / (Cout,) biases. */
+int cc_yolo_load(cc_yolo* h, const char* name, const float* data, const int64_t* shape, int ndim);
+/* Packs the loaded tensors into the device layout ([Cout][kh][kw][Cin], storage dtype). Fails if
+ * any parameter of the graph is missing. */
+int cc_yolo_finalize(cc_yolo* h);
+/* YOLOv9.__call__ (yolov9.py:375-388) over a batch: frames (B,H,W,3) BGR, uint8 (frame_f32=0, the
+ * production path clearcam.py:582) or float32 (frame_f32=1, the MOT path run_mot.py:33);
+ * out (B,300,6) float32 [x1,y1,x2,y2,conf,cls] in source-frame pixels, suppressed rows zero.
+ * B=1 is exactly the reference call.  frames_on_device/out_on_device select host or device pointers. */
+int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int frame_f32,
+                   int frames_on_device, float* out, int out_on_device, void* stream);
+/* Parity taps: copy a named intermediate of the LAST detect call to host float32.
+ * names: "input" (B,Hn,Wn,3) | "p3","p4","p5" (B,H,W,C) | "raw0","raw1","raw2" (B,H,W,144) |
+ * "decoded" (B,A,6).  shape receives up to 4 dims; pass out=NULL to query the shape only. */
+int cc_yolo_get_tensor(cc_yolo* h, const char* name, float* out, int64_t* shape, int* ndim);
+/* GPU milliseconds of the last detect call's kernels (hipEvents on the launch stream). */
+int cc_yolo_last_gpu_ms(cc_yolo* h, float* ms);
+void cc_yolo_destroy(cc_yolo* h);
+
+/* Single-layer entry used by the parity tests: NHWC conv + bias + optional SiLU on device buffers.
+ * x (B,H,W,Cin) and out (B,Ho,Wo,Cout) in storage dtype `dtype`; w OIHW float32 host, bias host.
+ * groups>1 is densified to block-diagonal weights exactly as the detector does for the head convs. */
+int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, const float* w_oihw,
+                   const float* bias, int Cout, int k, int stride, int groups, int act, void* out_dev,
+                   int force_direct, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CLIP — stands behind `OpenCLIP.precompute_embedding(x)` (models/objects.py:94-133) and
+ * `encode_text(model, tokens)` (models/objects.py:145-186); tokenisation stays on the host
+ * (utils/clip_tokenizer.py).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cc_clip cc_clip;
+typedef struct {
+  int image_size, patch, v_width, v_layers, v_heads, v_mlp;
+  int t_ctx, t_vocab, t_width, t_layers, t_heads, t_mlp, embed;
+} cc_clip_config;   /* ViT-L/14: {224,14,1024,24,16,4096, 77,49408,768,12,12,3072, 768} */
+
+int cc_clip_create(cc_clip** h, const cc_clip_config* cfg, int dtype, int device);
+int cc_clip_load(cc_clip* h, const char* name, const float* data, const int64_t* shape, int ndim);
+int cc_clip_finalize(cc_clip* h);
+/* precompute_embedding: x (B,3,S,S) float32 normalised pixels -> out (B,embed) float32 unit-norm. */
+int cc_clip_encode_image(cc_clip* h, const float* x, int B, int x_on_device, float* out, int out_on_device, void* stream);
+/* encode_text: tokens (B,t_ctx) int32 (SOT ... EOT, zero padded) -> out (B,embed) float32 unit-norm.
+ * The reference only ever passes B=1 and picks row argmax(tokens) (= EOT) of batch 0. */
+int cc_clip_encode_text(cc_clip* h, const int32_t* tokens, int B, float* out, int out_on_device, void* stream);
+int cc_clip_last_gpu_ms(cc_clip* h, float* ms);
+void cc_clip_destroy(cc_clip* h);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedding index — stands behind the scoring loop of `ObjectFinder.search`
+ * (models/objects.py:365-376: sim = img_emb @ text_emb.T per item) over a device-resident matrix.
+ * Path filtering / best-per-track-id / sorting of the reference stay in the Python shim.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cc_index cc_index;
+int cc_index_create(cc_index** h, int dim, int64_t capacity, int device);
+int cc_index_add(cc_index* h, const float* emb, int64_t n, int on_device);       /* append n rows (n,dim) f32 */
+int cc_index_size(cc_index* h, int64_t* n);
+int cc_index_scores(cc_index* h, const float* q, int Q, float* scores, int on_device, void* stream); /* (Q,N) */
+/* top-k per query by score (ties: lower row id first): idx (Q,k) int32, score (Q,k) f32; rows past N: -1/-inf */
+int cc_index_search(cc_index* h, const float* q, int Q, int k, int32_t* idx, float* score, int on_device, void* stream);
+void cc_index_destroy(cc_index* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
