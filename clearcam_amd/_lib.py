@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libclearcam_hip.so")
 SYMBOLS = [
     "cc_last_error", "cc_version", "cc_device_count",
     "cc_yolo_create", "cc_yolo_load", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_get_tensor",
-    "cc_yolo_last_gpu_ms", "cc_yolo_destroy", "cc_conv2d_nhwc",
+    "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_destroy", "cc_conv2d_nhwc",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
     "cc_clip_last_gpu_ms", "cc_clip_destroy",
     "cc_index_create", "cc_index_add", "cc_index_size", "cc_index_scores", "cc_index_search", "cc_index_destroy",
@@ -50,6 +50,7 @@ def lib() -> C.CDLL:
         "cc_yolo_detect": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_yolo_get_tensor": [vp, C.c_char_p, vp, i64p, ip],
         "cc_yolo_last_gpu_ms": [vp, fp],
+        "cc_yolo_profile": [vp, C.c_int, fp, C.POINTER(C.c_double), ip],
         "cc_conv2d_nhwc": [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, vp, C.c_int, vp],
         "cc_clip_create": [C.POINTER(vp), C.POINTER(ClipConfig), C.c_int, C.c_int],

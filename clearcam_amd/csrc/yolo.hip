@@ -36,7 +36,7 @@ static const Arch kArch[] = {
 };
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
-struct PackedConv { void* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 0; };
+struct PackedConv { void* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 0; double macs_px = 0; };
 
 struct Buf { int H, W, C; bool f32; size_t off; };
 struct View { int buf; int coff; int C; };
@@ -45,6 +45,7 @@ struct In { View v; int shift; };
 struct Op {
   int kind;  // 0 conv, 1 pool, 2 decode, 3 nms
   ConvP conv; PoolP pool; DecodeP dec; NmsP nms;
+  double alg_macs = 0;   // algorithmic multiply-accumulates of this launch (no padding / densification)
 };
 
 struct Plan {
@@ -112,6 +113,7 @@ static PackedConv pack_convs(int dt, const std::vector<const HostTensor*>& ws, c
   int n0 = 0;
   for (size_t t = 0; t < ws.size(); ++t) {
     const int co = (int)ws[t]->shape[0], cig = (int)ws[t]->shape[1], g = groups[t], cog = co / g;
+    pc.macs_px += (double)co * cig * k * k;
     for (int n = 0; n < co; ++n) {
       const int grp = n / cog;
       for (int c = 0; c < cig; ++c)
@@ -191,6 +193,7 @@ struct Builder {
     if (res) { const Buf& rb = P->bufs[res->buf]; c.res = (const void*)(intptr_t)res->buf; c.res_cstride = rb.C; c.res_coff = res->coff; c.res_f32 = rb.f32; }
     else { c.res = (const void*)(intptr_t)-1; }
     c.act = act;
+    op.alg_macs = (double)c.B * c.Ho * c.Wo * pc.macs_px;
     P->ops.push_back(op);
   }
 
@@ -560,6 +563,64 @@ int cc_yolo_last_gpu_ms(cc_yolo* h, float* ms) {
   CC_CHECK(h && ms && h->last, "no detect call yet");
   CC_HIP(hipEventSynchronize(h->ev1));
   CC_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  CC_API_END
+}
+
+int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step, int* n_conv_launches) {
+  CC_API_BEGIN
+  CC_CHECK(h && ms && h->last && iters > 0, "bad argument / no detect call yet");
+  Plan* P = h->last;
+  CC_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t n = P->ops.size();
+  std::vector<hipEvent_t> ev(2 * n);
+  for (auto& e : ev) CC_HIP(hipEventCreate(&e));
+  double acc[4] = {0, 0, 0, 0}, macs = 0; int nconv = 0;
+  for (int it = 0; it < iters; ++it) {
+    for (size_t i = 0; i < n; ++i) {
+      const Op& op = P->ops[i];
+      CC_HIP(hipEventRecord(ev[2 * i], s));
+      if (op.kind == 0) launch_conv(h->dtype, op.conv, s);
+      else if (op.kind == 1) launch_pool(h->dtype, op.pool, s);
+      else if (op.kind == 2) launch_decode(op.dec, s);
+      else launch_topk_nms(op.nms, s);
+      CC_HIP(hipEventRecord(ev[2 * i + 1], s));
+    }
+    CC_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; ++i) {
+      float t = 0; CC_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+      acc[P->ops[i].kind] += t;
+    }
+  }
+  for (const Op& op : P->ops) if (op.kind == 0) { macs += op.alg_macs; ++nconv; }
+  if (const char* path = getenv("CLEARCAM_PROFILE_CSV")) {   // per-launch table for tuning
+    FILE* f = fopen(path, "w");
+    if (f) {
+      fprintf(f, "op,kind,ms,M,Cout,Ktot,ks,stride,Cin,alg_gmac,tflops,gbytes_min,gbs\n");
+      for (size_t i = 0; i < n; ++i) {
+        const Op& op = P->ops[i];
+        float t = 0; hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
+        if (op.kind == 0) {
+          const ConvP& c = op.conv; const double M = (double)c.B * c.Ho * c.Wo;
+          const double es = dtype_size(h->dtype);
+          const double bytes = (double)c.B * (c.Hin >> c.s0.shift) * (c.Win >> c.s0.shift) * c.s0.C * es + (double)c.B * (c.Hin >> c.s1.shift) * (c.Win >> c.s1.shift) * c.s1.C * es
+                             + M * c.Cout * (c.out_f32 ? 4 : es) + (c.res ? M * c.Cout * es : 0) + (double)c.Cout * c.Ktot * es;
+          fprintf(f, "%zu,conv,%.4f,%.0f,%d,%d,%d,%d,%d,%.4f,%.1f,%.4f,%.0f\n", i, t, M, c.Cout, c.Ktot, c.ks, c.stride, c.Cin,
+                  op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9);
+        } else if (op.kind == 1) {
+          const PoolP& q = op.pool; const double es = dtype_size(h->dtype);
+          const double bytes = ((double)q.B * q.H * q.W + (double)q.B * q.Ho * q.Wo) * q.C * es;
+          fprintf(f, "%zu,pool%d_k%d_s%d,%.4f,%.0f,%d,0,%d,%d,%d,0,0,%.4f,%.0f\n", i, q.mode, q.k, q.stride, t, (double)q.B * q.Ho * q.Wo, q.C, q.k, q.stride, q.C,
+                  bytes / 1e9, bytes / (t * 1e-3) / 1e9);
+        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : "topk_nms", t);
+      }
+      fclose(f);
+    }
+  }
+  for (auto& e : ev) hipEventDestroy(e);
+  for (int k = 0; k < 4; ++k) ms[k] = (float)(acc[k] / iters);
+  if (alg_macs_per_step) *alg_macs_per_step = macs;
+  if (n_conv_launches) *n_conv_launches = nconv;
   CC_API_END
 }
 

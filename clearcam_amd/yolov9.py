@@ -104,6 +104,13 @@ class YOLOv9:
         _lib.check(_lib.lib().cc_yolo_last_gpu_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def profile(self, iters: int = 3) -> dict:
+        """Per-kernel-family GPU time of the last plan (hipEvents around every launch, eager replay)."""
+        ms, macs, n = (C.c_float * 4)(), C.c_double(), C.c_int()
+        _lib.check(_lib.lib().cc_yolo_profile(self._h, iters, ms, C.byref(macs), C.byref(n)))
+        return {"conv_ms": ms[0], "pool_ms": ms[1], "decode_ms": ms[2], "nms_ms": ms[3],
+                "alg_macs_per_step": macs.value, "conv_launches": n.value}
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().cc_yolo_destroy(self._h)

@@ -54,6 +54,10 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
 int cc_yolo_get_tensor(cc_yolo* h, const char* name, float* out, int64_t* shape, int* ndim);
 /* GPU milliseconds of the last detect call's kernels (hipEvents on the launch stream). */
 int cc_yolo_last_gpu_ms(cc_yolo* h, float* ms);
+/* Eager replay of the last plan's launch list, `iters` times, with a hipEvent pair around every launch
+ * on the launch stream.  ms[4] = average per-step milliseconds of {conv/GEMM, pooling, decode, top-k+NMS};
+ * alg_macs_per_step = algorithmic multiply-accumulates of the conv launches (padding excluded). */
+int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step, int* n_conv_launches);
 void cc_yolo_destroy(cc_yolo* h);
 
 /* Single-layer entry used by the parity tests: NHWC conv + bias + optional SiLU on device buffers.
