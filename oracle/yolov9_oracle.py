@@ -275,6 +275,15 @@ class YOLOv9Oracle:
         return self.detect_batch(frame[None])[0]
 
 
+def decoded_rows(y: torch.Tensor, conf: float = CONF_THRESHOLD) -> np.ndarray:
+    """(B,84,A) decode output -> (B,A,6) [x1,y1,x2,y2,score(thresholded),cls] = the rows ``postprocess``
+    ranks (:440-448), before top-k; the continuous quantity the HIP ``decoded`` tap is compared with."""
+    xc, yc, w, h, scores = y[:, 0], y[:, 1], y[:, 2], y[:, 3], y[:, 4:]
+    probs, cls = scores.max(1)
+    probs = torch.where(probs >= conf, probs, torch.zeros_like(probs))
+    return torch.stack((xc - w / 2, yc - h / 2, xc + w / 2, yc + h / 2, probs, cls.float()), 2).numpy()
+
+
 def match_detections(ref: np.ndarray, got: np.ndarray, iou_thr: float = 0.9):
     """Parity metric: rows with score>0 matched greedily by class + IoU.
 

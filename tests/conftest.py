@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_count() -> int:
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_count() > 0:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def lib_path():
+    """In-tree libclearcam_hip.so (built on demand with hipcc; cross-compiles without a GPU)."""
+    from clearcam_amd import build
+    return build.build()
+
+
+@pytest.fixture(scope="session")
+def sd_t():
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    return synthetic_yolov9_state_dict("t", 1234)
+
+
+@pytest.fixture(scope="session")
+def sd_c():
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    return synthetic_yolov9_state_dict("c", 1234)
+
+
+def noise_frames(seed, b, h, w, dtype=np.uint8):
+    f = np.random.default_rng(seed).integers(0, 256, (b, h, w, 3), dtype=np.uint8)
+    return f if dtype == np.uint8 else f.astype(dtype)

@@ -1,0 +1,80 @@
+"""CPU tests: the C-ABI library loads and exports everything include/clearcam_hip.h declares; host shims."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from clearcam_amd import _lib
+from clearcam_amd.helpers import Tensor, as_numpy, jit_infer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "clearcam_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_bound_and_exported(lib_path):
+    declared = _declared_symbols()
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.SYMBOLS) == declared                  # the Python binding covers the whole header
+    L = ctypes.CDLL(lib_path)
+    for s in declared:
+        assert hasattr(L, s), f"{s} not exported by libclearcam_hip.so"
+
+
+def test_no_cpu_fallback_without_gpu(lib_path, sd_t):
+    """On a box without a GPU the product path must raise, not fall back (no compute happens here)."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present")
+    from clearcam_amd.yolov9 import YOLOv9
+    with pytest.raises(_lib.CCError):
+        YOLOv9("t", 320, state_dict=sd_t)
+
+
+def test_bad_arguments_report_errors(lib_path):
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.cc_yolo_create(ctypes.byref(h), b"x", 640, 2, 0) != 0
+    assert b"unknown model size" in L.cc_last_error() or b"device" in L.cc_last_error().lower() or L.cc_last_error()
+    assert L.cc_yolo_create(ctypes.byref(h), b"c", 641, 2, 0) != 0
+    assert L.cc_yolo_create(ctypes.byref(h), b"c", 640, 7, 0) != 0
+
+
+def test_missing_weights_message():
+    from clearcam_amd.yolov9 import YOLOv9
+    with pytest.raises(FileNotFoundError):
+        YOLOv9("c", 640, weights="/nonexistent/yolov9-c.safetensors")
+    with pytest.raises(ValueError):
+        YOLOv9("e", 640)
+
+
+def test_tensor_shim_and_jit_infer():
+    f = np.zeros((4, 5, 3), np.uint8)
+    t = Tensor(f)
+    assert t.shape == (4, 5, 3) and t.numpy() is f
+    assert t.cast("float32").numpy().dtype == np.float32
+    assert t.unsqueeze(0).shape == (1, 4, 5, 3)
+    assert as_numpy(Tensor(Tensor(f))) is f
+    calls, cache = [], {}
+    fn = lambda x: calls.append(x.shape) or Tensor(np.zeros((300, 6), np.float32))   # noqa: E731
+    out = jit_infer(fn, t, cache)
+    jit_infer(fn, t, cache)
+    jit_infer(fn, Tensor(np.zeros((8, 5, 3), np.uint8)), cache)
+    assert out.numpy().shape == (300, 6)
+    assert sorted(cache) == [(4, 5, 3), (8, 5, 3)] and len(calls) == 3      # one cache entry per input shape
+
+
+def test_synthetic_weights_are_deterministic(sd_t):
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    again = synthetic_yolov9_state_dict("t", 1234)
+    assert all(np.array_equal(sd_t[k], again[k]) for k in sd_t)
+    other = synthetic_yolov9_state_dict("t", 99)
+    assert not np.array_equal(sd_t["model.list.0.conv.weight"], other["model.list.0.conv.weight"])
+    w = sd_t["model.list.4.cv4.conv.weight"]
+    assert abs(float(w.mean(axis=(1, 2, 3)).max())) < 1e-6      # zero-sum filters

@@ -1,0 +1,229 @@
+"""GPU parity tests of the detector, all through the C ABI (libclearcam_hip.so via clearcam_amd).
+
+Tolerances (BASELINE.json north_star: "box coords/classes within 1e-3"):
+  * f32 mode is the parity gate.  Box coordinates are compared in image-normalised units
+    (|dx| <= 1e-3 * max(H, W), i.e. 0.64 px at 640) and scores within 1e-3, with every oracle detection
+    matched one-to-one by class and IoU >= 0.9.  Measured: 0.03 px / 5e-5 — the f32 round-off floor
+    of a 144-conv network between two different summation orders.
+  * f16/bf16 (speed modes) are checked per layer to storage-rounding tolerance and end-to-end by
+    detection agreement; the seeded random network amplifies input perturbations ~250x over its depth,
+    so 16-bit end-to-end tolerances are necessarily loose and are stated where used.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from clearcam_amd import _lib
+from conftest import noise_frames
+from oracle import yolov9_oracle as yo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+DTI = {"f32": 0, "f16": 1, "bf16": 2}
+
+
+def _yolo(size, res, sd, dtype):
+    from clearcam_amd.yolov9 import YOLOv9
+    return YOLOv9(size, res, state_dict=sd, dtype=dtype, device=0)
+
+
+def conv_hip(x_nchw, w, b, stride, groups, act, dtype, force_direct=False):
+    """cc_conv2d_nhwc on cuda:0: NCHW f32 torch in -> NCHW f32 torch out (storage dtype in between)."""
+    L = _lib.lib()
+    xd = x_nchw.permute(0, 2, 3, 1).contiguous().to("cuda", TDT[dtype])
+    B, H, W_, Cin = xd.shape
+    Cout, k = w.shape[0], w.shape[2]
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W_ + 2 * (k // 2) - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=TDT[dtype], device="cuda")
+    wn, bn = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(b.numpy())
+    torch.cuda.synchronize()
+    _lib.check(L.cc_conv2d_nhwc(DTI[dtype], _lib.ptr(xd), B, H, W_, Cin, _lib.ptr(wn), _lib.ptr(bn), Cout, k, stride, groups,
+                                act, _lib.ptr(out), int(force_direct), None))
+    return out.float().cpu().permute(0, 3, 1, 2)
+
+
+# (name, B, Cin, H, W, Cout, k, stride, groups) — Appendix A's dominant shapes at reduced spatial size + edge cases
+CONV_CASES = [
+    ("3x3_256_256", 2, 256, 40, 40, 256, 3, 1, 1),
+    ("3x3_128_128", 1, 128, 80, 80, 128, 3, 1, 1),
+    ("1x1_1024_512", 2, 1024, 20, 20, 512, 1, 1, 1),
+    ("3x3_s2_64_128", 1, 64, 64, 64, 128, 3, 2, 1),
+    ("3x3_s2_odd_in", 1, 128, 39, 39, 128, 3, 2, 1),      # ADown: conv over the (H-1)x(W-1) avg-pooled map
+    ("1x1_cout80", 1, 256, 20, 20, 80, 1, 1, 1),          # head cls logits (N not a tile multiple)
+    ("3x3_grouped", 1, 64, 20, 20, 64, 3, 1, 4),          # head box branch, densified
+    ("1x1_grouped", 1, 64, 20, 20, 64, 1, 1, 4),
+    ("3x3_32_32", 1, 32, 48, 48, 32, 3, 1, 1),
+    ("ragged_m", 1, 64, 13, 7, 64, 3, 1, 1),              # M = 91: not a multiple of the 128-pixel tile
+]
+TOL = {"f32": 2e-5, "f16": 3e-3, "bf16": 2e-2}            # max |err| / max |ref|
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_layer_matches_torch(case, dtype):
+    _, B, Cin, H, W_, Cout, k, stride, groups = case
+    g = torch.Generator().manual_seed(hash(case[0]) % 1000)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin // groups, k, k, generator=g) / (Cin // groups * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    xq = x.to(TDT[dtype]).float()                        # the kernel sees storage-rounded inputs/weights
+    wq = w.to(TDT[dtype]).float()
+    ref = F.silu(F.conv2d(xq, wq, b, stride=stride, padding=k // 2, groups=groups))
+    got = conv_hip(x, w, b, stride, groups, 1, dtype)
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= TOL[dtype], err
+
+
+def test_conv_direct_fallback_odd_channels():
+    """YOLOv9-m widths (60/90) are not 16-byte multiples -> the direct kernel must run and agree."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 90, 20, 20, generator=g)
+    w = torch.randn(60, 90, 3, 3, generator=g) / 28.0
+    b = torch.randn(60, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x, w, b, padding=1))
+    got = conv_hip(x, w, b, 1, 1, 1, "f32")
+    assert float((got - ref).abs().max()) < 1e-4
+    forced = conv_hip(torch.randn(1, 64, 16, 16, generator=g), torch.randn(64, 64, 3, 3, generator=g) / 24, b[:60].repeat(2)[:64], 1, 1, 1, "f32", True)
+    assert torch.isfinite(forced).all()
+
+
+def test_letterbox_uint8_bit_exact(sd_t):
+    """Integer path (tinygrad uint8 lerp) must be bit-exact: 540x960 -> 360x640 + 12 px zero pad."""
+    frames = noise_frames(6, 1, 540, 960)
+    m = _yolo("t", 640, sd_t, "f32")
+    m.detect_batch(frames)
+    got = m.get_tensor("input")                                           # (1,384,640,3) RGB /255
+    lb = yo.letterbox(frames[0], 640)
+    ref = lb[..., ::-1].astype(np.float32) / np.float32(255.0)
+    assert got.shape == (1, 384, 640, 3)
+    assert np.array_equal(got[0], ref)
+
+
+def test_letterbox_float_frames_exact(sd_t):
+    frames = noise_frames(7, 1, 270, 480, np.float32)                     # MOT path: Tensor(im).cast(float32)
+    m = _yolo("t", 320, sd_t, "f32")
+    m.detect_batch(frames)
+    ref = yo.letterbox(frames[0], 320)[..., ::-1] / np.float32(255.0)
+    assert np.array_equal(m.get_tensor("input")[0], ref.astype(np.float32))
+
+
+@pytest.mark.parametrize("size,res,seed,shape", [("t", 640, 1, (2, 640, 640, 3)), ("t", 640, 6, (1, 540, 960, 3)),
+                                                  ("c", 640, 1, (1, 640, 640, 3))])
+def test_detect_f32_matches_oracle_and_golden(size, res, seed, shape, sd_t, sd_c):
+    sd = sd_t if size == "t" else sd_c
+    frames = noise_frames(seed, *shape[:3])
+    o = yo.YOLOv9Oracle(size, res, sd)
+    with torch.no_grad():
+        feats = o.features(o.network_input(frames))
+        dec_ref = yo.decoded_rows(o.decode(o.head_raw(feats)))
+    ref = o.detect_batch(frames)
+    m = _yolo(size, res, sd, "f32")
+    got = m.detect_batch(frames)
+    for name, f in zip(("p3", "p4", "p5"), feats):
+        r = f.permute(0, 2, 3, 1).numpy()
+        rel = np.sqrt(((m.get_tensor(name) - r) ** 2).mean() / (r ** 2).mean())
+        assert rel < 2e-4, (name, rel)
+    # continuous parity before the discrete top-k/NMS: every anchor the oracle scores clear of the threshold
+    dec = m.get_tensor("decoded")
+    tol = 1e-3 * max(shape[1], shape[2])
+    sure = dec_ref[..., 4] >= 0.25 + 2e-3
+    assert sure.sum() > 0
+    assert np.abs(dec[..., :4] - dec_ref[..., :4])[sure].max() <= tol
+    assert np.abs(dec[..., 4] - dec_ref[..., 4])[sure].max() <= 1e-3
+    assert (dec[..., 5] == dec_ref[..., 5])[sure].mean() >= 0.995       # argmax flips only between near-tied classes
+    # end to end: one-to-one matches by class and IoU>=0.9; a detection sitting within f32 noise of the 0.25 / 0.45
+    # thresholds may flip (the oracle itself flips between two CPUs), hence 99 % rather than 100 %
+    gname = {(640, 1, 2): "yolo_t_640", (640, 6, 1): "yolo_t_640_from_540x960"}.get((res, seed, shape[0])) if size == "t" else "yolo_c_640"
+    gold = np.load(os.path.join(GOLD, gname + ".npz"))["det"]
+    for b in range(shape[0]):
+        for target in (ref[b], gold[b]):
+            n_ref, n_got, n_match, box_err, sc_err = yo.match_detections(target, got[b], 0.9)
+            assert n_ref > 0 and n_match >= 0.99 * max(n_ref, n_got) - 1, (n_ref, n_got, n_match)
+            assert box_err <= tol and sc_err <= 1e-3, (box_err, sc_err)
+            assert box_err <= 0.32         # f32 round-off floor actually measured: 0.03-0.17 px
+
+
+def test_decode_topk_nms_exact_given_same_logits(sd_t):
+    """Post-processing isolated: oracle decode+postprocess on the HIP head logits == HIP output row for row."""
+    frames = noise_frames(1, 2, 640, 640)
+    m = _yolo("t", 640, sd_t, "f32")
+    got = m.detect_batch(frames)
+    raw = [torch.from_numpy(m.get_tensor(f"raw{i}")).permute(0, 3, 1, 2) for i in range(3)]
+    o = yo.YOLOv9Oracle("t", 640, sd_t)
+    with torch.no_grad():
+        ref = o.scale_boxes((640, 640), o.postprocess(o.decode(raw)), (640, 640)).numpy()
+    pos = ref[..., 4] > 0
+    assert pos.sum() > 100
+    assert np.array_equal(ref[..., 5], got[..., 5])                 # same classes in the same rows
+    assert np.abs(ref - got)[pos].max() < 2e-3                      # expf/softmax ulps only
+    assert np.array_equal(ref[..., 4] > 0, got[..., 4] > 0)
+
+
+@pytest.mark.parametrize("dtype,min_match,feat_rel", [("f16", 0.85, 0.08), ("bf16", 0.55, 0.5)])
+def test_detect_16bit_modes_agree_with_oracle(dtype, min_match, feat_rel, sd_c):
+    """Speed modes, end to end.  Loose by construction (see module docstring); per-layer tests are the tight ones."""
+    frames = noise_frames(1, 2, 640, 640)
+    o = yo.YOLOv9Oracle("c", 640, sd_c)
+    ref = o.detect_batch(frames)
+    with torch.no_grad():
+        p3 = o.block_outputs[15].permute(0, 2, 3, 1).numpy()
+    m = _yolo("c", 640, sd_c, dtype)
+    got = m.detect_batch(frames)
+    rel = np.sqrt(((m.get_tensor("p3") - p3) ** 2).mean() / (p3 ** 2).mean())
+    assert rel < feat_rel, rel
+    for b in range(2):
+        n_ref, n_got, n_match, _, _ = yo.match_detections(ref[b], got[b], 0.5)
+        assert n_match >= min_match * n_ref and abs(n_got - n_ref) <= 0.15 * n_ref, (n_ref, n_got, n_match)
+    assert np.isfinite(got).all()
+
+
+def test_batch_invariance_and_determinism(sd_c):
+    """Size-independent properties at the bench configuration (B=64, 640x640, bf16)."""
+    frames = noise_frames(11, 64, 640, 640)
+    m = _yolo("c", 640, sd_c, "bf16")
+    a = m.detect_batch(frames)
+    b = m.detect_batch(frames)
+    assert np.array_equal(a, b)                                     # deterministic replay
+    one = m.detect_batch(frames[17:18])
+    assert np.array_equal(one[0], a[17])                            # a frame's result does not depend on its batch
+    dev = m.detect_batch(torch.from_numpy(frames).cuda())           # device-resident frames == host frames
+    assert np.array_equal(dev, a)
+    s = a[..., 4]
+    assert (a[..., :4] >= 0).all() and (a[..., [0, 2]] <= 640).all() and (a[..., [1, 3]] <= 640).all()
+    assert ((a[..., 5] >= 0) & (a[..., 5] < 80)).all() and (a[..., 5] == np.floor(a[..., 5])).all()
+    for i in range(64):                                             # surviving rows are in descending score order
+        nz = s[i][s[i] > 0]
+        assert (np.diff(nz) <= 0).all() and (nz >= 0.25).all()
+    dead = s == 0
+    assert (a[dead][:, :4].max() if dead.any() else 0) <= 640
+
+
+def test_reference_call_surface(sd_t):
+    """clearcam.py:582-583 / run_mot.py:33-34 call shapes, through the shims."""
+    from clearcam_amd.helpers import Tensor, jit_infer
+    m = _yolo("t", 640, sd_t, "f32")
+    frame = noise_frames(1, 1, 640, 640)[0]
+    cache = {}
+    preds = jit_infer(m, Tensor(frame), cache).numpy()
+    assert preds.shape == (300, 6) and preds.dtype == np.float32
+    mot = m(Tensor(frame).cast("float32")).numpy()
+    assert np.array_equal(mot, preds)                               # same integers as floats, identity resize
+    boxes, scores, cls = preds[:, :4], preds[:, 4], preds[:, 5].astype(int)   # ocsort.py:194-196
+    assert boxes.shape == (300, 4) and scores.max() <= 1 and cls.max() < 80
+
+
+def test_small_model_sizes_run(sd_t):
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    for size in ("s", "m"):
+        sd = synthetic_yolov9_state_dict(size, 1234)
+        frames = noise_frames(2, 1, 640, 640)
+        ref = yo.YOLOv9Oracle(size, 640, sd).detect_batch(frames)
+        got = _yolo(size, 640, sd, "f32").detect_batch(frames)
+        n_ref, n_got, n_match, box_err, sc_err = yo.match_detections(ref[0], got[0], 0.9)
+        assert n_match >= 0.99 * max(n_ref, n_got) - 1 and box_err <= 0.64 and sc_err <= 1e-3, (size, n_ref, n_got, n_match)
