@@ -1,0 +1,314 @@
+// CLIP tower kernels other than the GEMMs: LayerNorm, patchify, token assembly, embedding gather,
+// fused attention (MFMA for f16/bf16, exact-f32 VALU for parity mode), L2 normalise.
+// Reference: models/objects.py:94-186 (tinygrad tensor ops); GEMMs go through conv_mfma.hip.
+#include "kernels.h"
+#include "mfma.h"
+
+namespace cc {
+
+ConvP gemm_params(const void* A, int lda, int M, int K, const void* W, const float* bias, int N, void* out, int ldc,
+                  int out_f32, int act, const void* res, int ldres, int res_f32) {
+  ConvP c{};
+  c.s0 = Src{A, 1, M, lda, 0, K, 0};
+  c.s1 = Src{A, 1, 1, 0, 0, 0, 0};
+  c.B = 1; c.Hin = 1; c.Win = M; c.Cin = K; c.Ho = 1; c.Wo = M; c.Cout = N;
+  c.ks = 1; c.stride = 1; c.pad = 0; c.Ktot = K;
+  c.w = W; c.bias = bias; c.out = out; c.out_cstride = ldc; c.out_coff = 0; c.out_f32 = out_f32;
+  c.res = res; c.res_cstride = ldres; c.res_coff = 0; c.res_f32 = res_f32; c.act = act;
+  return c;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- LayerNorm: one wave per row, D <= 1024 ------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= p.rows) return;
+  const float* x = p.in + (long)(p.row_index ? p.row_index[row] : row) * p.in_row_stride;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const int j = lane + 64 * i; v[i] = j < p.D ? x[j] : 0.f; s += v[i]; }
+  const float mean = wave_sum(s) / (float)p.D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const int j = lane + 64 * i; const float d = j < p.D ? v[i] - mean : 0.f; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.D + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = lane + 64 * i;
+    if (j < p.D) {
+      const float y = (v[i] - mean) * rstd * p.w[j] + p.b[j];
+      if (p.out_f32) reinterpret_cast<float*>(p.out)[(size_t)row * p.D + j] = y;
+      else reinterpret_cast<T*>(p.out)[(size_t)row * p.D + j] = from_f32<T>(y);
+    }
+  }
+}
+void launch_layernorm(int dt, const LnP& p, hipStream_t stream) {
+  CC_CHECK(p.D <= 1024, "layernorm: D > 1024");
+  const dim3 grid((p.rows + 3) / 4), block(256);
+  if (dt == F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, stream, p);
+  else if (dt == F16) hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, stream, p);
+  CC_HIP(hipGetLastError());
+}
+
+// ---- patchify: conv 14x14/s14 as a GEMM operand (objects.py:95-97) --------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void patchify_kernel(const PatchP p) {
+  const int g = p.S / p.patch, pp = p.patch * p.patch;
+  const size_t total = (size_t)p.B * g * g * p.Kpad;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx % p.Kpad);
+  const size_t row = idx / p.Kpad;
+  float v = 0.f;
+  if (k < 3 * pp) {
+    const int c = k / pp, r = k - c * pp, kh = r / p.patch, kw = r - kh * p.patch;
+    const int b = (int)(row / (g * g)), pi = (int)(row - (size_t)b * g * g), py = pi / g, px = pi - py * g;
+    v = p.x[(((size_t)b * 3 + c) * p.S + py * p.patch + kh) * p.S + px * p.patch + kw];
+  }
+  reinterpret_cast<T*>(p.out)[idx] = from_f32<T>(v);
+}
+void launch_patchify(int dt, const PatchP& p, hipStream_t stream) {
+  const int g = p.S / p.patch;
+  const size_t total = (size_t)p.B * g * g * p.Kpad;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dt == F32) hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, stream, p);
+  else if (dt == F16) hipLaunchKernelGGL(patchify_kernel<f16_t>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, block, 0, stream, p);
+  CC_HIP(hipGetLastError());
+}
+
+// ---- token assembly + ln_pre ------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void assemble_ln_kernel(const AssembleP p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= p.B * p.L) return;
+  const int b = row / p.L, t = row - b * p.L;
+  const T* patch = reinterpret_cast<const T*>(p.patches) + ((size_t)b * (p.L - 1) + (t > 0 ? t - 1 : 0)) * p.D;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = lane + 64 * i;
+    v[i] = j < p.D ? (t == 0 ? p.cls[j] : to_f32<T>(patch[j])) + p.pos[(size_t)t * p.D + j] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)p.D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const int j = lane + 64 * i; const float d = j < p.D ? v[i] - mean : 0.f; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.D + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = lane + 64 * i;
+    if (j < p.D) p.out[(size_t)row * p.D + j] = (v[i] - mean) * rstd * p.w[j] + p.b[j];
+  }
+}
+void launch_assemble_ln(int dt, const AssembleP& p, hipStream_t stream) {
+  CC_CHECK(p.D <= 1024, "assemble: D > 1024");
+  const dim3 grid((p.B * p.L + 3) / 4), block(256);
+  if (dt == F32) hipLaunchKernelGGL(assemble_ln_kernel<float>, grid, block, 0, stream, p);
+  else if (dt == F16) hipLaunchKernelGGL(assemble_ln_kernel<f16_t>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(assemble_ln_kernel<bf16_t>, grid, block, 0, stream, p);
+  CC_HIP(hipGetLastError());
+}
+
+// ---- token embedding gather + positional -----------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const EmbedP p) {
+  const size_t total = (size_t)p.B * p.L * p.D;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx % p.D);
+  const size_t row = idx / p.D;
+  const int t = (int)(row % p.L);
+  p.out[idx] = p.table[(size_t)p.tokens[row] * p.D + j] + p.pos[(size_t)t * p.D + j];
+}
+void launch_embed(const EmbedP& p, hipStream_t stream) {
+  const size_t total = (size_t)p.B * p.L * p.D;
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+  CC_HIP(hipGetLastError());
+}
+
+// ---- L2 normalise -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_kernel(const NormP p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= p.rows) return;
+  float* x = p.x + (size_t)row * p.D;
+  float s = 0.f;
+  for (int j = lane; j < p.D; j += 64) s += x[j] * x[j];
+  const float n = sqrtf(wave_sum(s)) + p.eps;
+  for (int j = lane; j < p.D; j += 64) x[j] = x[j] / n;
+}
+void launch_l2norm(const NormP& p, hipStream_t stream) {
+  hipLaunchKernelGGL(l2norm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, stream, p);
+  CC_HIP(hipGetLastError());
+}
+
+// ---- attention, 16-bit storage: S^T = K Q^T and O^T = V^T P^T on MFMA --------------------------------
+// One workgroup = (batch b, head h, 64 queries); wave w owns 16 queries.  The whole K (rows of 128 B, chunk-
+// swizzled like the GEMM tiles) and V^T (keys permuted so each PV operand is one 16-B read) of the head sit in
+// LDS: L <= 288 keys (ViT-L/14 has 257, the text tower 77) -> no online-softmax tiling over keys is needed.
+// Computing the TRANSPOSED scores puts one query per lane column (lane&15), so the softmax reduction is
+// 4*NF register values + two cross-lane steps, and the exponentiated P is already in MFMA B-operand layout.
+template <class T, int NF>    // NF = padded keys / 16
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnP p) {
+  constexpr int LP = NF * 16, VS = LP + 8;          // padded keys, V^T row stride (elements)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* ldsK = reinterpret_cast<uint4*>(smem);                         // [LP][8 chunks]
+  T* ldsVt = reinterpret_cast<T*>(smem + (size_t)LP * 128);             // [64][VS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+  const int D3 = 3 * p.D;
+  const T* base = reinterpret_cast<const T*>(p.qkv) + (size_t)b * p.L * D3 + h * 64;
+
+  for (int idx = tid; idx < LP * 8; idx += 256) {
+    const int key = idx >> 3, chunk = idx & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (key < p.L) {
+      kv = *reinterpret_cast<const uint4*>(base + (size_t)key * D3 + p.D + chunk * 8);
+      vv = *reinterpret_cast<const uint4*>(base + (size_t)key * D3 + 2 * p.D + chunk * 8);
+    }
+    ldsK[key * 8 + (chunk ^ ((key >> 1) & 7))] = kv;
+    // key = 32f + 16hh + 4g + r  ->  position 32f + 8g + 4hh + r  (PV k-slot order, see below)
+    const int pos = (key & ~31) + ((key >> 2) & 3) * 8 + ((key >> 4) & 1) * 4 + (key & 3);
+    const T* ve = reinterpret_cast<const T*>(&vv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ldsVt[(chunk * 8 + e) * VS + pos] = ve[e];
+  }
+  const int ql = lane & 15, g = lane >> 4, q = q0 + ql;
+  uint4 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    qf[ks] = q < p.L ? *reinterpret_cast<const uint4*>(base + (size_t)q * D3 + (ks * 4 + g) * 8) : make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  f32x4 s[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = f * 16 + ql;
+      Mma<T>::run(ldsK[row * 8 + ((ks * 4 + g) ^ ((row >> 1) & 7))], qf[ks], s[f]);
+    }
+  }
+  // s[f][r] = <k_{16f+4g+r}, q_{ql}>
+  float mx = -INFINITY;
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = f * 16 + g * 4 + r;
+      float v = s[f][r] * p.scale;
+      if (key >= p.L || (p.causal && key > q)) v = -INFINITY;
+      s[f][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float e = __expf(s[f][r] - mx); s[f][r] = e; sum += e; }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+
+  f32x4 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f2 = 0; f2 < NF / 2; ++f2) {
+    // B operand k-slot (g, j): j<4 -> key 32f2 + 4g + j, j>=4 -> key 32f2 + 16 + 4g + (j-4); V^T was staged in that order
+    alignas(16) T pk[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pk[r] = from_f32<T>(s[2 * f2][r]); pk[4 + r] = from_f32<T>(s[2 * f2 + 1][r]); }
+    const uint4 pf = *reinterpret_cast<const uint4*>(pk);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint4 vf = *reinterpret_cast<const uint4*>(ldsVt + (d * 16 + ql) * VS + f2 * 32 + g * 8);
+      Mma<T>::run(vf, pf, o[d]);
+    }
+  }
+  if (q < p.L) {
+    const float inv = 1.0f / sum;
+    T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q) * p.D + h * 64;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      alignas(8) T t4[4] = {from_f32<T>(o[d][0] * inv), from_f32<T>(o[d][1] * inv), from_f32<T>(o[d][2] * inv), from_f32<T>(o[d][3] * inv)};
+      *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = *reinterpret_cast<uint2*>(t4);
+    }
+  }
+}
+
+// ---- attention, any storage type, f32 VALU math: one wave per query (parity mode / fallback) ------------
+template <class T>
+__global__ __launch_bounds__(256) void attn_simple_kernel(const AttnP p) {
+  constexpr int LMAX = 320;
+  __shared__ float qs[4][64];
+  __shared__ float ps[4][LMAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = min(blockIdx.x * 4 + wave, p.L - 1);
+  const bool live = blockIdx.x * 4 + wave < p.L;
+  const int D3 = 3 * p.D;
+  const T* base = reinterpret_cast<const T*>(p.qkv) + (size_t)b * p.L * D3 + h * 64;
+  qs[wave][lane] = to_f32<T>(base[(size_t)q * D3 + lane]);
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = lane; j < p.L; j += 64) {
+    const T* k = base + (size_t)j * D3 + p.D;
+    float dot = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) dot = fmaf(qs[wave][d], to_f32<T>(k[d]), dot);
+    float v = dot * p.scale;
+    if (p.causal && j > q) v = -INFINITY;
+    ps[wave][j] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < p.L; j += 64) { const float e = expf(ps[wave][j] - mx); ps[wave][j] = e; sum += e; }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float o = 0.f;
+  for (int j = 0; j < p.L; ++j) o = fmaf(ps[wave][j] / sum, to_f32<T>(base[(size_t)j * D3 + 2 * p.D + lane]), o);
+  if (live) reinterpret_cast<T*>(p.ctx)[((size_t)b * p.L + q) * p.D + h * 64 + lane] = from_f32<T>(o);
+}
+
+template <class T, int NF> static void launch_attn_mfma(const AttnP& p, hipStream_t stream) {
+  const size_t lds = (size_t)NF * 16 * 128 + (size_t)64 * (NF * 16 + 8) * sizeof(T);
+  static bool configured = false;
+  if (!configured) {
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<T, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((attn_mfma_kernel<T, NF>), dim3((p.L + 63) / 64, p.H, p.B), dim3(256), lds, stream, p);
+}
+
+void launch_attention(int dt, const AttnP& p, hipStream_t stream) {
+  CC_CHECK(p.D == p.H * 64, "attention: head dim must be 64");
+  CC_CHECK(p.L <= 288, "attention: more than 288 tokens");
+  if (dt == F32) {
+    hipLaunchKernelGGL(attn_simple_kernel<float>, dim3((p.L + 3) / 4, p.H, p.B), dim3(256), 0, stream, p);
+  } else if (dt == F16) {
+    if (p.L <= 96) launch_attn_mfma<f16_t, 6>(p, stream); else launch_attn_mfma<f16_t, 18>(p, stream);
+  } else {
+    if (p.L <= 96) launch_attn_mfma<bf16_t, 6>(p, stream); else launch_attn_mfma<bf16_t, 18>(p, stream);
+  }
+  CC_HIP(hipGetLastError());
+}
+
+}  // namespace cc

@@ -14,33 +14,9 @@
 // (8 lanes = one row) and the MFMA-fragment ds_read_b128 (16 rows x one chunk column) conflict-free.
 // f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32) with the k-slots of a 16-B chunk spread over 4 MFMAs.
 #include "kernels.h"
+#include "mfma.h"
 
 namespace cc {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-
-template <class T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static __device__ __forceinline__ void run(const uint4& w, const uint4& x, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
-  }
-};
-template <> struct Mma<f16_t> {
-  static __device__ __forceinline__ void run(const uint4& w, const uint4& x, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static __device__ __forceinline__ void run(const uint4& w, const uint4& x, f32x4& acc) {
-    const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], xf[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], xf[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], xf[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], xf[3], acc, 0, 0, 0);
-  }
-};
 
 template <class T> __device__ __forceinline__ float act_silu(float x) {
   if constexpr (sizeof(T) == 4) return x / (1.0f + expf(-x));
@@ -57,7 +33,7 @@ template <class T> __device__ __forceinline__ void store4(void* base, size_t idx
   if constexpr (sizeof(T) == 4) {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
-    T t[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+    alignas(8) T t[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
     *reinterpret_cast<uint2*>(reinterpret_cast<T*>(base) + idx) = *reinterpret_cast<uint2*>(t);
   }
 }

@@ -1,0 +1,275 @@
+// Device-resident embedding index: brute-force cosine scan + top-k.
+//
+// Stands behind the scoring loop of ObjectFinder.search (models/objects.py:365-376), where the reference
+// evaluates `(img_embedding @ text_embedding.T).item()` once per stored crop in a Python loop.  Here the
+// (N, dim) float32 matrix lives in HBM and one query costs one streaming pass over it (HBM-bound:
+// N*dim*4 bytes), followed by a two-stage radix-select top-k.  Scores are exact f32 dot products
+// (sequential fma per lane + wave tree), so ranking ties break by row id exactly as a stable sort would.
+#include <algorithm>
+#include <memory>
+#include <vector>
+#include "kernels.h"
+#include "../../include/clearcam_hip.h"
+
+using namespace cc;
+
+struct cc_index {
+  int dim = 0, device = 0; int64_t capacity = 0, n = 0;
+  float* emb = nullptr;
+  hipStream_t stream = nullptr;
+  float* q_dev = nullptr; int q_cap = 0;
+  float* scores = nullptr; size_t scores_cap = 0;
+  unsigned long long* cand = nullptr; size_t cand_cap = 0;
+  int* idx_dev = nullptr; float* sc_dev = nullptr; size_t out_cap = 0;
+};
+
+namespace {
+
+constexpr int kChunk = 16384;     // rows per stage-1 block
+constexpr int kMaxK = 1024;
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// scores[q][row] = <emb[row], query[q]>; one wave per row (grid-stride), up to 4 queries per pass.
+template <int QB>
+__global__ __launch_bounds__(256) void scores_kernel(const float* __restrict__ emb, const float* __restrict__ q, float* __restrict__ out,
+                                                      long n, int dim, int nq) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  for (long row = wave; row < n; row += nwaves) {
+    const float* e = emb + row * dim;
+    float acc[QB];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) acc[c] = 0.f;
+    for (int j = lane * 4; j < dim; j += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(e + j);
+#pragma unroll
+      for (int c = 0; c < QB; ++c) {
+        if (c < nq) {
+          const float4 w = *reinterpret_cast<const float4*>(q + (long)c * dim + j);
+          acc[c] = fmaf(v.x, w.x, acc[c]); acc[c] = fmaf(v.y, w.y, acc[c]); acc[c] = fmaf(v.z, w.z, acc[c]); acc[c] = fmaf(v.w, w.w, acc[c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+      const float s = wsum(acc[c]);
+      if (lane == 0 && c < nq) out[(long)c * n + row] = s;
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned ordered(float f) {          // monotone float -> uint
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unordered(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// Block-wide exact top-K of `count` unique 64-bit keys (key(i) for i in [0,count)): MSB-first radix select of the
+// K-th largest key, then collection of every key >= it into `sel` (unsorted; K entries, zero padded).
+template <class KeyFn>
+__device__ void block_topk(KeyFn key, long count, int K, unsigned long long* sel, unsigned* hist,
+                           unsigned long long* s_prefix, int* s_k, unsigned* s_cnt) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < K; i += nt) sel[i] = 0ull;
+  if (tid == 0) { *s_prefix = 0ull; *s_k = (int)(count < K ? count : K); *s_cnt = 0; }
+  __syncthreads();
+  if (count <= 0) return;
+  for (int byte = 7; byte >= 0; --byte) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long prefix = *s_prefix;
+    const int sh = 8 * (byte + 1);
+    for (long i = tid; i < count; i += nt) {
+      const unsigned long long k = key(i);
+      if (byte == 7 || (k >> sh) == (prefix >> sh)) atomicAdd(&hist[(unsigned)(k >> (8 * byte)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+      const unsigned s = h0 + h1 + h2 + h3;
+      unsigned suf = s;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_down(suf, off, 64); if (tid + off < 64) suf += t; }
+      const unsigned above = suf - s, kk = (unsigned)*s_k;
+      if (above < kk && kk <= suf) {
+        unsigned cum = above; int v = 4 * tid + 3;
+        const unsigned hh[4] = {h0, h1, h2, h3};
+        for (int qd = 3; qd >= 0; --qd) { if (cum + hh[qd] >= kk) { v = 4 * tid + qd; break; } cum += hh[qd]; }
+        *s_prefix = prefix | ((unsigned long long)v << (8 * byte));
+        *s_k = (int)(kk - cum);
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned long long thr = *s_prefix;
+  for (long i = tid; i < count; i += nt) {
+    const unsigned long long k = key(i);
+    if (k >= thr) { const unsigned pos = atomicAdd(s_cnt, 1u); if (pos < (unsigned)K) sel[pos] = k; }
+  }
+  __syncthreads();
+}
+
+// stage 1: per (query, chunk of rows) top-K keys -> cand[q][chunk][K]
+__global__ __launch_bounds__(1024) void topk_stage1(const float* __restrict__ scores, long n, int K, unsigned long long* __restrict__ cand) {
+  __shared__ unsigned hist[256]; __shared__ unsigned long long s_prefix; __shared__ int s_k; __shared__ unsigned s_cnt;
+  __shared__ unsigned long long sel[kMaxK];
+  const int chunk = blockIdx.x, q = blockIdx.y;
+  const long base = (long)chunk * kChunk, count = min((long)kChunk, n - base);
+  const float* s = scores + (long)q * n + base;
+  auto key = [&](long i) { return ((unsigned long long)ordered(s[i]) << 32) | (unsigned)(~(unsigned)(base + i)); };
+  block_topk(key, count, K, sel, hist, &s_prefix, &s_k, &s_cnt);
+  unsigned long long* o = cand + ((size_t)q * gridDim.x + chunk) * K;
+  for (int i = threadIdx.x; i < K; i += blockDim.x) o[i] = sel[i];
+}
+
+// stage 2: merge candidates of one query, sort descending, emit (row id, score)
+__global__ __launch_bounds__(1024) void topk_stage2(const unsigned long long* __restrict__ cand, long ncand, int K, int* __restrict__ idx, float* __restrict__ score) {
+  __shared__ unsigned hist[256]; __shared__ unsigned long long s_prefix; __shared__ int s_k; __shared__ unsigned s_cnt;
+  __shared__ unsigned long long sel[kMaxK];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const unsigned long long* c = cand + (size_t)q * ncand;
+  auto key = [&](long i) { return c[i]; };      // zero keys (padding) sort last and never beat a real key
+  for (int i = tid; i < kMaxK; i += blockDim.x) sel[i] = 0ull;
+  __syncthreads();
+  block_topk(key, ncand, K, sel, hist, &s_prefix, &s_k, &s_cnt);
+  for (int k = 2; k <= kMaxK; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int ixj = tid ^ j;
+      if (ixj > tid) {
+        const unsigned long long x = sel[tid], y = sel[ixj];
+        const bool desc = (tid & k) == 0;
+        if (desc ? (x < y) : (x > y)) { sel[tid] = y; sel[ixj] = x; }
+      }
+      __syncthreads();
+    }
+  if (tid < K) {
+    const unsigned long long k = sel[tid];
+    if (k == 0ull) { idx[(size_t)q * K + tid] = -1; score[(size_t)q * K + tid] = -INFINITY; }
+    else { idx[(size_t)q * K + tid] = (int)(~(unsigned)(k & 0xffffffffull)); score[(size_t)q * K + tid] = unordered((unsigned)(k >> 32)); }
+  }
+}
+
+void ensure(void** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes) return;
+  if (*p) hipFree(*p);
+  CC_HIP(hipMalloc(p, bytes + 256));
+  *cap = bytes;
+}
+
+void upload_queries(cc_index* h, const float* q, int Q, int on_device, hipStream_t s) {
+  if (h->q_cap < Q) { if (h->q_dev) hipFree(h->q_dev); CC_HIP(hipMalloc((void**)&h->q_dev, (size_t)Q * h->dim * 4 + 256)); h->q_cap = Q; }
+  CC_HIP(hipMemcpyAsync(h->q_dev, q, (size_t)Q * h->dim * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+}
+
+void compute_scores(cc_index* h, int Q, hipStream_t s) {
+  ensure((void**)&h->scores, &h->scores_cap, (size_t)Q * h->n * 4);
+  const int blocks = (int)std::min<int64_t>((h->n + 3) / 4, 256 * 16);
+  for (int q0 = 0; q0 < Q; q0 += 4) {
+    const int nq = std::min(4, Q - q0);
+    hipLaunchKernelGGL(scores_kernel<4>, dim3(blocks), dim3(256), 0, s, h->emb, h->q_dev + (size_t)q0 * h->dim, h->scores + (size_t)q0 * h->n,
+                       (long)h->n, h->dim, nq);
+  }
+  CC_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+#define CC_API_BEGIN try {
+#define CC_API_END                                                         \
+  return 0; }                                                              \
+  catch (const cc::Error& e) { cc::set_error(e.what()); return e.code; }   \
+  catch (const std::exception& e) { cc::set_error(e.what()); return -1; }
+
+extern "C" {
+
+int cc_index_create(cc_index** h, int dim, int64_t capacity, int device) {
+  CC_API_BEGIN
+  CC_CHECK(h && dim > 0 && dim % 4 == 0 && capacity > 0, "bad argument (dim must be a multiple of 4)");
+  int n = 0; CC_HIP(hipGetDeviceCount(&n));
+  CC_CHECK(n > 0 && device >= 0 && device < n, "no such HIP device");
+  CC_HIP(hipSetDevice(device));
+  std::unique_ptr<cc_index> x(new cc_index());
+  x->dim = dim; x->capacity = capacity; x->device = device;
+  CC_HIP(hipMalloc((void**)&x->emb, (size_t)capacity * dim * 4 + 256));
+  CC_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+  *h = x.release();
+  CC_API_END
+}
+
+int cc_index_add(cc_index* h, const float* emb, int64_t n, int on_device) {
+  CC_API_BEGIN
+  CC_CHECK(h && (emb || n == 0) && n >= 0, "bad argument");
+  CC_CHECK(h->n + n <= h->capacity, "index capacity exceeded");
+  CC_HIP(hipSetDevice(h->device));
+  if (n) CC_HIP(hipMemcpy(h->emb + (size_t)h->n * h->dim, emb, (size_t)n * h->dim * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  h->n += n;
+  CC_API_END
+}
+
+int cc_index_size(cc_index* h, int64_t* n) {
+  CC_API_BEGIN
+  CC_CHECK(h && n, "null argument");
+  *n = h->n;
+  CC_API_END
+}
+
+int cc_index_scores(cc_index* h, const float* q, int Q, float* scores, int on_device, void* stream) {
+  CC_API_BEGIN
+  CC_CHECK(h && q && scores && Q > 0, "bad argument");
+  CC_HIP(hipSetDevice(h->device));
+  if (h->n == 0) return 0;
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  upload_queries(h, q, Q, on_device, s);
+  compute_scores(h, Q, s);
+  CC_HIP(hipMemcpyAsync(scores, h->scores, (size_t)Q * h->n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  if (!on_device) CC_HIP(hipStreamSynchronize(s));
+  CC_API_END
+}
+
+int cc_index_search(cc_index* h, const float* q, int Q, int k, int32_t* idx, float* score, int on_device, void* stream) {
+  CC_API_BEGIN
+  CC_CHECK(h && q && idx && score && Q > 0, "bad argument");
+  CC_CHECK(k > 0 && k <= kMaxK, "k must be in [1, 1024]");
+  CC_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const size_t ob = (size_t)Q * k;
+  if (h->out_cap < ob) {
+    if (h->idx_dev) hipFree(h->idx_dev);
+    if (h->sc_dev) hipFree(h->sc_dev);
+    CC_HIP(hipMalloc((void**)&h->idx_dev, ob * 4 + 256)); CC_HIP(hipMalloc((void**)&h->sc_dev, ob * 4 + 256)); h->out_cap = ob;
+  }
+  const int nchunk = (int)std::max<int64_t>(1, (h->n + kChunk - 1) / kChunk);
+  ensure((void**)&h->cand, &h->cand_cap, (size_t)Q * nchunk * k * 8);
+  if (h->n > 0) {
+    upload_queries(h, q, Q, on_device, s);
+    compute_scores(h, Q, s);
+    hipLaunchKernelGGL(topk_stage1, dim3(nchunk, Q), dim3(1024), 0, s, h->scores, (long)h->n, k, h->cand);
+  } else {
+    CC_HIP(hipMemsetAsync(h->cand, 0, (size_t)Q * nchunk * k * 8, s));
+  }
+  hipLaunchKernelGGL(topk_stage2, dim3(Q), dim3(1024), 0, s, h->cand, (long)nchunk * k, k, h->idx_dev, h->sc_dev);
+  CC_HIP(hipGetLastError());
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  CC_HIP(hipMemcpyAsync(idx, h->idx_dev, ob * 4, kind, s));
+  CC_HIP(hipMemcpyAsync(score, h->sc_dev, ob * 4, kind, s));
+  if (!on_device) CC_HIP(hipStreamSynchronize(s));
+  CC_API_END
+}
+
+void cc_index_destroy(cc_index* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void* p : {(void*)h->emb, (void*)h->q_dev, (void*)h->scores, (void*)h->cand, (void*)h->idx_dev, (void*)h->sc_dev}) if (p) hipFree(p);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+}  // extern "C"

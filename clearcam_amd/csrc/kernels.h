@@ -52,4 +52,41 @@ struct NmsP {                 // top-300 + mask NMS + scale_boxes: detection/yol
 };
 void launch_topk_nms(const NmsP& p, hipStream_t stream);
 
+// ---- CLIP towers (clip_kernels.hip) -------------------------------------------------------------
+// Plain GEMM through the conv kernel:  out[M][N] = act(A[M][K] W[N][K]^T + bias) (+res).
+ConvP gemm_params(const void* A, int lda, int M, int K, const void* W, const float* bias, int N, void* out, int ldc,
+                  int out_f32, int act, const void* res, int ldres, int res_f32);
+
+struct LnP {                  // LayerNorm(eps 1e-5, biased var, affine): models/objects.py:105,123,129,153,176,182
+  const float* in; long in_row_stride; const int* row_index;   // row r reads in + (row_index ? row_index[r] : r) * in_row_stride
+  const float* w; const float* b;
+  void* out; int out_f32;     // [rows][D]
+  int rows, D;
+};
+void launch_layernorm(int dt, const LnP& p, hipStream_t stream);
+
+struct PatchP { const float* x; void* out; int B, S, patch, Kpad; };   // (B,3,S,S) f32 -> (B*g*g, Kpad), k = c*p*p + kh*p + kw
+void launch_patchify(int dt, const PatchP& p, hipStream_t stream);
+
+struct AssembleP {            // cat(class_embedding, patches) + positional_embedding -> ln_pre   (objects.py:98-102)
+  const void* patches;        // (B*(L-1), D) storage dtype
+  const float* cls; const float* pos; const float* w; const float* b;
+  float* out;                 // (B*L, D) f32 residual stream
+  int B, L, D;
+};
+void launch_assemble_ln(int dt, const AssembleP& p, hipStream_t stream);
+
+struct EmbedP { const int* tokens; const float* table; const float* pos; float* out; int B, L, D; };   // objects.py:148-149
+void launch_embed(const EmbedP& p, hipStream_t stream);
+
+struct AttnP {                // softmax(q k^T / sqrt(dh)) v per head, dh = 64   (objects.py:110-119,160-171)
+  const void* qkv;            // (B*L, 3*D) storage dtype: [q | k | v]
+  void* ctx;                  // (B*L, D)
+  int B, L, H, D; int causal; float scale;
+};
+void launch_attention(int dt, const AttnP& p, hipStream_t stream);
+
+struct NormP { float* x; int rows, D; float eps; };   // x / (||x||_2 + eps)   (objects.py:132,186)
+void launch_l2norm(const NormP& p, hipStream_t stream);
+
 }  // namespace cc
