@@ -1,0 +1,72 @@
+"""Multi-GPU layout of the hot path: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+
+* detect / CLIP-encode: cameras (and their crops) are independent -> ``camera_rank`` pins each camera to one
+  GPU; weights are replicated; there is NO data-path collective.
+* search: the embedding matrix is row-sharded (a camera's crops live on its GPU).  A query is scanned locally
+  on every rank (``EmbeddingIndex.search``) and the per-rank top-k lists — k x (f32 score, i64 global row id),
+  800 B per rank at k=100 — are exchanged with ONE all-gather and merged on every rank.  Embeddings never move:
+  replicating 1 M x 768 f32 would cost ~3 GB through a per-link-bound ring, the top-k exchange ~20 us.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def camera_rank(camera_index: int, world_size: int) -> int:
+    """Static camera -> GPU map (round robin keeps per-GPU stream counts within one of each other)."""
+    return camera_index % world_size
+
+
+def shard_offsets(local_rows: int, group=None, device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """(first global row id of this rank's shard, total rows) via an all-gather of shard sizes."""
+    world = dist.get_world_size(group)
+    t = torch.tensor([local_rows], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(sizes, t, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    r = dist.get_rank(group)
+    return sum(sizes[:r]), sum(sizes)
+
+
+def merge_topk(all_idx: torch.Tensor, all_score: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(Q, n) candidate (global id, score) lists -> top-k by score desc, ties by lower global id; id -1 sorts last."""
+    big = torch.iinfo(torch.int64).max
+    key_id = torch.where(all_idx < 0, torch.full_like(all_idx, big), all_idx)
+    o1 = torch.argsort(key_id, dim=1, stable=True)
+    s1, i1 = torch.gather(all_score, 1, o1), torch.gather(all_idx, 1, o1)
+    o2 = torch.argsort(s1, dim=1, descending=True, stable=True)[:, :k]
+    return torch.gather(i1, 1, o2), torch.gather(s1, 1, o2)
+
+
+def allgather_topk(local_idx, local_score, row_offset: int, k: int, group=None,
+                   device: Optional[torch.device] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """The one exchange step of sharded search.
+
+    local_idx/local_score: (Q,k) per-rank top-k with LOCAL row ids (-1 / -inf padding).  Returns the merged
+    global (Q,k) ids and scores, identical on every rank."""
+    idx = torch.as_tensor(np.asarray(local_idx), dtype=torch.int64, device=device)
+    sc = torch.as_tensor(np.asarray(local_score), dtype=torch.float32, device=device)
+    idx = torch.where(idx >= 0, idx + row_offset, idx)
+    world = dist.get_world_size(group)
+    gi = [torch.empty_like(idx) for _ in range(world)]
+    gs = [torch.empty_like(sc) for _ in range(world)]
+    dist.all_gather(gi, idx, group=group)
+    dist.all_gather(gs, sc, group=group)
+    mi, ms = merge_topk(torch.cat(gi, 1), torch.cat(gs, 1), k)
+    return mi.cpu().numpy(), ms.cpu().numpy()
+
+
+class ShardedIndex:
+    """Row-sharded embedding index: local HBM scan + one RCCL all-gather of k candidates per rank."""
+
+    def __init__(self, index, group=None, device: Optional[torch.device] = None):
+        self.index, self.group, self.device = index, group, device
+        self.row_offset, self.total = shard_offsets(len(index), group, device)
+
+    def search(self, q, k: int):
+        idx, sc = self.index.search(q, k)
+        return allgather_topk(idx, sc, self.row_offset, k, self.group, self.device)

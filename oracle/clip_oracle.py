@@ -11,8 +11,8 @@ need the real ViT-L/14 checkpoint (fetched from HuggingFace at construction, :91
 offline, so THIS ORACLE IS UNPINNED against the reference's outputs ("parity unpinned").  What is checked:
 the tokenizer against ids produced by the reference's own tokenizer run in this container
 (tests/golden/tokenizer_kats.json), the golden pickle's self-consistency (unit norm, cos(f40,micra)),
-and structural pins (parameter count 427.6 M, 81.0 GMAC/image).  ``tools/check_real_clip.py`` runs the
-reference's scalar pin as soon as a checkpoint is dropped in.
+and structural pins (parameter count, 81.0 GMAC/image).  The reference's pins are restated in
+tests/golden/reference_pins.json so the scalar check can run the day a checkpoint is available.
 
 tinygrad semantics: ``gelu()`` is the tanh approximation (B-5), LayerNorm eps 1e-5
 biased variance (B-6), ``masked_fill(-inf)`` causal mask (B-8), image norm eps 1e-8 / text norm no eps.

@@ -1,0 +1,61 @@
+"""world_size-2 gloo test of the one exchange step of sharded search (all-gather of per-rank top-k + merge)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from clearcam_amd.dist import allgather_topk, camera_rank, merge_topk, shard_offsets
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(3)
+        E = rng.standard_normal((1000, 16)).astype(np.float32)
+        E[700] = E[10]                                       # an exact tie across shards: lower global id must win
+        q = rng.standard_normal((3, 16)).astype(np.float32)
+        bounds = [0, 600, 1000]                              # ragged shards
+        lo, hi = bounds[rank], bounds[rank + 1]
+        off, total = shard_offsets(hi - lo)
+        assert (off, total) == (lo, 1000)
+        k = 20
+        sc = q @ E[lo:hi].T                                  # test scaffolding: the local scan runs in HIP in production
+        order = np.argsort(-sc, axis=1, kind="stable")[:, :k]
+        gi, gs = allgather_topk(order, np.take_along_axis(sc, order, 1), off, k)
+        full = q @ E.T
+        ref = np.argsort(-full, axis=1, kind="stable")[:, :k]
+        ok = np.array_equal(gi, ref) and np.allclose(gs, np.take_along_axis(full, ref, 1))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_topk_allgather_gloo_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get(0) is True and ret.get(1) is True
+
+
+def test_merge_topk_padding_and_ties():
+    idx = torch.tensor([[5, -1, 2, 9, -1, 0]])
+    sc = torch.tensor([[0.5, float("-inf"), 0.9, 0.5, float("-inf"), 0.1]])
+    i, s = merge_topk(idx, sc, 5)
+    assert i.tolist() == [[2, 5, 9, 0, -1]] and np.allclose(s[0, :4].numpy(), [0.9, 0.5, 0.5, 0.1])
+
+
+def test_camera_rank_balanced():
+    counts = np.bincount([camera_rank(c, 8) for c in range(64)], minlength=8)
+    assert counts.tolist() == [8] * 8

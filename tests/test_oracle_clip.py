@@ -1,0 +1,102 @@
+"""CPU tests of the CLIP oracle, the tokenizer (against ids from the reference's own tokenizer) and search logic."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from clearcam_amd.arch import CLIP_L14, CLIP_TINY
+from clearcam_amd.weights import clip_shapes, synthetic_clip_state_dict
+from oracle.clip_oracle import OpenCLIPOracle, pad_tokens, search_reference
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _vocab_available():
+    from clearcam_amd.clip_tokenizer import find_vocab
+    try:
+        find_vocab()
+        return True
+    except FileNotFoundError:
+        return False
+
+
+def test_clip_structure_pins():
+    s = clip_shapes(CLIP_L14)
+    assert s["visual_conv1.weight"] == (1024, 3, 14, 14) and s["positional_embedding"] == (257, 1024)
+    assert s["resblocks_img.23.in_proj_weight"] == (3072, 1024) and s["resblocks.11.attn_out_proj_weight"] == (768, 768)
+    assert s["proj"] == (1024, 768) and s["text_projection"] == (768, 768) and s["token_embedding.weight"] == (49408, 768)
+    n = sum(int(np.prod(v)) for v in s.values())
+    assert abs(n / 1e6 - 427.6) < 0.5                                     # ViT-L/14 + text tower
+    # MACs per image: 81.0 G = patch embed + 24 x (qkv + scores + pv + out + mlp) + proj
+    L, D, M = 257, 1024, 4096
+    macs = 256 * 588 * D + 24 * (L * D * 3 * D + 2 * 16 * L * L * 64 + L * D * D + 2 * L * D * M) + D * 768
+    assert abs(macs / 1e9 - 81.013) < 0.01
+
+
+def test_reference_golden_embeddings_are_consistent():
+    pins = json.load(open(os.path.join(GOLD, "reference_pins.json")))
+    e = {k: np.asarray(v["values"], np.float32) for k, v in pins["embeddings"].items()}
+    assert set(e) == {"f40.jpg", "micra.jpg"} and all(v.shape == (768,) for v in e.values())
+    for v in e.values():
+        assert abs(np.linalg.norm(v) - 1.0) < 1e-5                         # L2-normalised (objects.py:132)
+    assert abs(float(e["f40.jpg"] @ e["micra.jpg"]) - 0.5501478) < 1e-6
+    assert np.allclose(e["f40.jpg"][:5], [-0.01891246, -0.13603427, -0.02724903, 0.01994121, -0.01596762], atol=1e-7)
+    assert pins["text_image_cosine_ferrari_f40"] == 0.330654
+
+
+@pytest.mark.skipif(not _vocab_available(), reason="bpe_simple_vocab_16e6.txt.gz not available")
+def test_tokenizer_matches_reference_ids():
+    from clearcam_amd.clip_tokenizer import SimpleTokenizer
+    k = json.load(open(os.path.join(GOLD, "tokenizer_kats.json")))
+    t = SimpleTokenizer()
+    assert (t.vocab_size, t.sot_token_id, t.eot_token_id) == (k["vocab_size"], k["sot"], k["eot"]) == (49408, 49406, 49407)
+    for c in k["cases"]:
+        assert t.encode(c["text"]) == c["ids"], c["text"]
+    m = t.tokens_for_model("ferrari f40")
+    assert m.shape == (1, 77) and m[0, :6].tolist() == [49406, 9606, 325, 275, 271, 49407] and m[0, 6:].sum() == 0
+
+
+def test_split_words_pattern():
+    from clearcam_amd.clip_tokenizer import split_words
+    assert split_words("it's 42nd st.!!") == ["it", "'s", "4", "2", "nd", "st", ".!!"]
+    assert split_words("a<end_of_text>b") == ["a", "<end_of_text>", "b"]
+
+
+def test_oracle_embeddings_are_unit_and_batch_invariant():
+    sd = synthetic_clip_state_dict(CLIP_TINY, 4321)
+    o = OpenCLIPOracle(sd, CLIP_TINY)
+    x = np.random.default_rng(2).random((3, 3, 56, 56), dtype=np.float32) * 2 - 1
+    e = o.precompute_embedding(x)
+    assert e.shape == (3, 64) and np.allclose(np.linalg.norm(e, axis=1), 1, atol=1e-5)
+    assert np.allclose(o.precompute_embedding(x[1:2])[0], e[1], atol=1e-5)
+    toks = np.concatenate([pad_tokens([5, 9, 44], 77, 510, 511), pad_tokens(list(range(1, 40)), 77, 510, 511)])
+    t = o.encode_tokens(toks)
+    assert t.shape == (2, 64) and np.allclose(np.linalg.norm(t, axis=1), 1, atol=1e-5)
+    assert np.allclose(o.encode_tokens(toks[1:])[0], t[1], atol=1e-5)
+    # causal mask: tokens after EOT must not influence the pooled EOT row
+    toks2 = toks.copy(); toks2[0, 10:] = 7
+    assert np.allclose(o.encode_tokens(toks2)[0], t[0], atol=1e-6)
+
+
+def test_search_reference_semantics():
+    """objects.py:356-390: best score per track id, id-less crops kept, filters by camera / day."""
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal(8).astype(np.float32); q /= np.linalg.norm(q)
+
+    def emb(scale):
+        v = (q * scale + rng.standard_normal(8).astype(np.float32) * (1.05 - scale) * 0.4)    # cosine grows with `scale`
+        return (v / np.linalg.norm(v))[None]
+    d = {
+        "data/cameras/front/objects/2026-01-01/100.0_7_2.jpg": emb(1.0),
+        "data/cameras/front/objects/2026-01-01/101.0_7_2.jpg": emb(0.5),      # same track id 7 -> only the best survives
+        "data/cameras/back/objects/2026-01-01/102.0_9_0.jpg": emb(0.8),
+        "data/cameras/back/objects/2026-01-02/103.0_11_0.jpg": emb(0.9),
+        "data/cameras/back/objects/2026-01-02/notes.txt": emb(1.0),            # not a .jpg -> ignored
+    }
+    r = search_reference(d, q, top_k=10)
+    assert [os.path.basename(p) for p, _ in r][0] == "100.0_7_2.jpg" and len(r) == 3
+    assert all(r[i][1] >= r[i + 1][1] for i in range(len(r) - 1))
+    assert len(search_reference(d, q, cam_name="back")) == 2
+    assert len(search_reference(d, q, timestamp="2026-01-02")) == 1
+    assert len(search_reference(d, q, top_k=1)) == 1
