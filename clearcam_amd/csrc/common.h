@@ -56,7 +56,27 @@ template <> __host__ __device__ inline float to_f32<bf16_t>(bf16_t v) { return b
 template <class T> __host__ __device__ inline T from_f32(float f);
 template <> __host__ __device__ inline float from_f32<float>(float f) { return f; }
 template <> __host__ __device__ inline f16_t from_f32<f16_t>(float f) { return (f16_t)f; }
-template <> __host__ __device__ inline bf16_t from_f32<bf16_t>(float f) { bf16_t r; r.v = f32_to_bf16_bits(f); return r; }
+template <> __host__ __device__ inline bf16_t from_f32<bf16_t>(float f) {
+  bf16_t r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  r.v = __builtin_bit_cast(uint16_t, (__bf16)f);      // v_cvt_pk_bf16_f32 (RNE) instead of ~7 integer VALU ops
+#else
+  r.v = f32_to_bf16_bits(f);
+#endif
+  return r;
+}
+
+// two f32 -> one dword of two storage-dtype values (low half = a): one v_cvt_pk_* on gfx950
+typedef float cc_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 cc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 cc_f16x2 __attribute__((ext_vector_type(2)));
+template <class T> __device__ inline uint32_t pack2(float a, float b);
+template <> __device__ inline uint32_t pack2<bf16_t>(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(cc_f32x2{a, b}, cc_bf16x2));
+}
+template <> __device__ inline uint32_t pack2<f16_t>(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(cc_f32x2{a, b}, cc_f16x2));
+}
 
 // host-side conversion of an f32 array into the storage dtype
 void convert_f32_to(int dt, const float* src, void* dst, size_t n);

@@ -6,35 +6,59 @@
 //
 // GEMM view: D[n][m] = sum_k W[n][k] * X[m][k];  m = output pixel, n = output channel, k = (tap, channel).
 // Weights are the MFMA A operand (rows n), activations the B operand (cols m), so each lane ends up
-// with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+// with 4 consecutive output channels of one pixel.
 //
 // Tile: 128 pixels x BN channels x 128 bytes of K (64 halfs / 32 floats) per step, 256 threads = 4 waves.
-// Staging: global -> registers (next tile, issued before the MFMAs of the current one) -> LDS rows of
-// 128 B whose eight 16-B chunks are XOR-swizzled by (row>>1)&7, which makes both the ds_write_b128
-// (8 lanes = one row) and the MFMA-fragment ds_read_b128 (16 rows x one chunk column) conflict-free.
-// f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32) with the k-slots of a 16-B chunk spread over 4 MFMAs.
+// * Staging: global_load_lds (16 B per lane, straight into LDS, no VGPR round trip), two LDS stages, one
+//   barrier per K step: step t+1 streams in while the MFMAs of step t run.  LDS rows are 128 B; the eight
+//   16-B chunks of a row are XOR-swizzled by (row>>1)&7.  The DMA writes lane-linear (wave base + lane*16),
+//   so the swizzle is applied to the per-lane SOURCE chunk and again on the fragment read; DMA writes
+//   (8 lanes = one row) and ds_read_b128 (16 rows x one chunk column) are both conflict-free.
+//   Halo / out-of-range lanes read a 16-byte zero page instead of branching.
+// * Instruction diet (rocprofv3 PMC: thin layers were VALU-bound, 2.1k VALU per tile-wave vs 64 MFMA):
+//   per-row base pointers and a 9-bit tap-validity mask are computed once per tile and a K step adds one
+//   per-thread delta (SIMPLE = single source, no upsample); f32->bf16/f16 uses v_cvt_pk_*; the activation
+//   is a compile-time branch of the epilogue.
+// * Epilogue: bias -> activation in registers, then (16-bit outputs) through a consumed LDS stage
+//   (chunk-swizzled) so that every pixel's BN channels leave as 16-byte-per-lane, line-contiguous stores;
+//   f32 outputs / residual adds store directly from registers.
+// * Tiles are issued in an XCD-aware order (bijective remap of blockIdx): all channel tiles of a pixel tile and
+//   neighbouring pixel tiles run on one XCD's L2.
+// * f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32) with the k-slots of a 16-B chunk spread over 4 MFMAs.
+#include <algorithm>
+#include <type_traits>
 #include "kernels.h"
 #include "mfma.h"
 
 namespace cc {
 
-template <class T> __device__ __forceinline__ float act_silu(float x) {
-  if constexpr (sizeof(T) == 4) return x / (1.0f + expf(-x));
-  else return x * __frcp_rn(1.0f + __expf(-x));
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+struct ConvAux {
+  float inv_hw, inv_wo;   // 1/(Ho*Wo), 1/Wo for divide-free pixel decomposition
+  int nt;                 // channel tiles per pixel tile
+  int is1x1;              // 1x1, stride 1, no pad, no upsample: input pixel index == output pixel index
+};
+
+template <class T, int ACT> __device__ __forceinline__ float activate(float x) {
+  if constexpr (ACT == 1) {            // SiLU
+    if constexpr (sizeof(T) == 4) return x / (1.0f + expf(-x));
+    else return x * __frcp_rn(1.0f + __expf(-x));
+  } else if constexpr (ACT == 2) {     // tinygrad Tensor.gelu(): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))  
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    if constexpr (sizeof(T) == 4) return 0.5f * x * (1.0f + tanhf(u));
+    else { const float e = __expf(2.0f * u); return 0.5f * x * (1.0f + (1.0f - 2.0f * __frcp_rn(e + 1.0f))); }
+  } else return x;
 }
-template <class T> __device__ __forceinline__ float act_gelu_tanh(float x) {
-  // tinygrad Tensor.gelu(): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))  
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  if constexpr (sizeof(T) == 4) return 0.5f * x * (1.0f + tanhf(u));
-  else { const float e = __expf(2.0f * u); return 0.5f * x * (1.0f + (1.0f - 2.0f * __frcp_rn(e + 1.0f))); }
+template <class T> __device__ __forceinline__ float activate_rt(float x, int act) {
+  return act == 1 ? activate<T, 1>(x) : (act == 2 ? activate<T, 2>(x) : x);
 }
 
 template <class T> __device__ __forceinline__ void store4(void* base, size_t idx, const float (&v)[4]) {
   if constexpr (sizeof(T) == 4) {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
-    alignas(8) T t[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
-    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(base) + idx) = *reinterpret_cast<uint2*>(t);
+    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(base) + idx) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
   }
 }
 template <class T> __device__ __forceinline__ void load4(const void* base, size_t idx, float (&v)[4]) {
@@ -48,67 +72,126 @@ template <class T> __device__ __forceinline__ void load4(const void* base, size_
   }
 }
 
-template <class T, int BN, int WM>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
+// LDS-DMA issue in inline asm: hipcc otherwise counts the DMA as an LDS write that may alias the next
+// ds_read and drains it (s_waitcnt vmcnt(0)) before the MFMA phase, serialising load and compute.  Hidden here,
+// the only wait is the explicit vmcnt(0) in front of each K-step barrier.  M0 = wave-uniform LDS byte address;
+// the hardware adds lane*16.  (cdna_hip_programming.md §5.7: M0 written in the same statement that uses it.)
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_wave_byte_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+// n / d for 0 <= n < 2^31 with quotient < 2^22, given inv ~ 1/d (float reciprocal + one-step correction)
+__device__ __forceinline__ int fdiv(int n, int d, float inv) {
+  int q = (int)((float)n * inv);
+  const int r = n - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
+
+// SIMPLE: one source, no upsample, ks <= 3  ->  hoisted row pointers + tap masks.  !SIMPLE: general path.
+template <class T, int BN, int WM, bool SIMPLE>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p, const ConvAux a) {
   constexpr int BM = 128, WN = 4 / WM;
   constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
   constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * E;                // elements per K step (128 bytes)
   constexpr int WR = BN / 32;              // weight rows staged per thread
-  __shared__ uint4 lds[(BM + BN) * 8];
-  uint4* ldsX = lds;
-  uint4* ldsW = lds + BM * 8;
+  constexpr int STAGE = (BM + BN) * 8;     // uint4 per stage
+  __shared__ uint4 lds[2 * STAGE];         // the only LDS object (K stages; stage 0 doubles as the epilogue tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int M = p.B * p.Ho * p.Wo;
-  const int nt = (p.Cout + BN - 1) / BN;
+  const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
+  const unsigned lds_base = lds_addr(lds);
 
-  // XCD-aware tile order: consecutive tiles (same pixel rows, all channel tiles) share one XCD's L2.
   int wg;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (wg / nt) * BM, n0 = (wg % nt) * BN;
+  const int mt_ = wg / a.nt;
+  const int m0 = mt_ * BM, n0 = (wg - mt_ * a.nt) * BN;
 
-  // ---- per-thread staging assignment: 16-B chunk column `chunk`, rows rowb + 32*i
-  const int chunk = tid & 7, rowb = tid >> 3;
-  int pb[4], ph0[4], pw0[4];
+  // ---- loader setup: LDS position `ppos` of rows prow + 32*i  <-  global chunk `chunk`
+  const int ppos = tid & 7, prow = tid >> 3;
+  const int chunk = ppos ^ ((prow >> 1) & 7);          // ((prow+32i)>>1)&7 is the same for every i
+  const char* rowp[4]; unsigned vmask[4];              // SIMPLE: byte address of (pixel (h0,w0), channel coff); tap-in-range bits
+  int pb[4], ph0[4], pw0[4];                           // general: batch index, top-left input coordinate
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + rowb + 32 * i;
-    if (m < M) {
-      const int hw = p.Ho * p.Wo;
-      const int b = m / hw, rem = m - b * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      pb[i] = b; ph0[i] = ho * p.stride - p.pad; pw0[i] = wo * p.stride - p.pad;
-    } else { pb[i] = 0; ph0[i] = -(1 << 28); pw0[i] = 0; }
-  }
-  int k0 = chunk * E;                      // this thread's k index inside the current K step
-  int kc, kr, ks_;                         // channel, tap row, tap col of k0
-  { const int tap = k0 / p.Cin; kc = k0 - tap * p.Cin; kr = tap / p.ks; ks_ = tap - kr * p.ks; }
-
-  uint4 xr[4], wr[WR];
-  auto issue_loads = [&]() {
-    const bool kok = k0 < p.Ktot;
-    const bool first = kc < p.s0.C;
-    const T* sp = reinterpret_cast<const T*>(first ? p.s0.ptr : p.s1.ptr);
-    const int sH = first ? p.s0.H : p.s1.H, sW = first ? p.s0.W : p.s1.W;
-    const int scs = first ? p.s0.cstride : p.s1.cstride, sco = first ? p.s0.coff : p.s1.coff;
-    const int ssh = first ? p.s0.shift : p.s1.shift;
-    const int cc = first ? kc : kc - p.s0.C;
+    const int m = m0 + prow + 32 * i;
+    if constexpr (SIMPLE) {
+      if (a.is1x1) {
+        rowp[i] = reinterpret_cast<const char*>(p.s0.ptr) + ((size_t)m * p.s0.cstride + p.s0.coff) * sizeof(T);
+        vmask[i] = m < M ? 1u : 0u;
+      } else {
+        const int mm = m < M ? m : 0;
+        const int b = fdiv(mm, hw, a.inv_hw), rem = mm - b * hw, ho = fdiv(rem, p.Wo, a.inv_wo), wo = rem - ho * p.Wo;
+        const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+        unsigned hm = 0, wm = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ih = ph0[i] + kr, iw = pw0[i] + ks_;
-      const bool ok = kok && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-      const size_t off = ((size_t)(pb[i] * sH + (ih >> ssh)) * sW + (iw >> ssh)) * scs + sco + cc;
-      xr[i] = ok ? *reinterpret_cast<const uint4*>(sp + off) : make_uint4(0, 0, 0, 0);
+        for (int r = 0; r < 3; ++r) {
+          hm |= (unsigned)(r < p.ks && (unsigned)(h0 + r) < (unsigned)p.Hin) << r;
+          wm |= (unsigned)(r < p.ks && (unsigned)(w0 + r) < (unsigned)p.Win) << r;
+        }
+        unsigned vm = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? wm << p.ks : 0u) | ((hm & 4u) ? wm << (2 * p.ks) : 0u);
+        vmask[i] = m < M ? vm : 0u;
+        rowp[i] = reinterpret_cast<const char*>(p.s0.ptr) +
+                  ((((long)b * p.s0.H + h0) * p.s0.W + w0) * (long)p.s0.cstride + p.s0.coff) * (long)sizeof(T);
+      }
+    } else {
+      if (m < M) {
+        const int b = fdiv(m, hw, a.inv_hw), rem = m - b * hw, ho = fdiv(rem, p.Wo, a.inv_wo), wo = rem - ho * p.Wo;
+        pb[i] = b; ph0[i] = ho * p.stride - p.pad; pw0[i] = wo * p.stride - p.pad;
+      } else { pb[i] = 0; ph0[i] = -(1 << 28); pw0[i] = 0; }
     }
-    const T* wp = reinterpret_cast<const T*>(p.w);
+  }
+  const char* wrow[WR]; unsigned wok = 0;
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int n = n0 + prow + 32 * i;
+    wrow[i] = reinterpret_cast<const char*>(p.w) + (size_t)n * p.Ktot * sizeof(T);
+    wok |= (n < p.Cout ? 1u : 0u) << i;
+  }
+  int k0 = chunk * E, kc, kr, ks_;                     // this thread's k index; its channel, tap row, tap col
+  if (k0 < p.Cin) { kc = k0; kr = 0; ks_ = 0; }
+  else { const int tap = k0 / p.Cin; kc = k0 - tap * p.Cin; kr = tap / p.ks; ks_ = tap - kr * p.ks; }
+
+  auto issue_loads = [&](int stage) {
+    const bool kok = k0 < p.Ktot;
+    // wave-uniform LDS byte address of this wave's 1 KiB slice of the stage (+ lane*16 added by the DMA)
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE + wave * 64) * 16u);
+    if constexpr (SIMPLE) {
+      const int tbit = kr * p.ks + ks_;
+      const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc) * (long)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = kok && ((vmask[i] >> tbit) & 1u);
+        glds16(ok ? static_cast<const void*>(rowp[i] + delta) : static_cast<const void*>(&g_zero16), sbase + i * 4096u);
+      }
+    } else {
+      const bool first = kc < p.s0.C;
+      const T* sp = reinterpret_cast<const T*>(first ? p.s0.ptr : p.s1.ptr);
+      const int scs = first ? p.s0.cstride : p.s1.cstride, sco = first ? p.s0.coff : p.s1.coff;
+      const int cc = first ? kc : kc - p.s0.C;
+      const int sH = first ? p.s0.H : p.s1.H, sW = first ? p.s0.W : p.s1.W, ssh = first ? p.s0.shift : p.s1.shift;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ih = ph0[i] + kr, iw = pw0[i] + ks_;
+        const bool ok = kok && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        const size_t off = ((size_t)(pb[i] * sH + (ih >> ssh)) * sW + (iw >> ssh)) * scs + sco + cc;
+        glds16(ok ? static_cast<const void*>(sp + off) : static_cast<const void*>(&g_zero16), sbase + i * 4096u);
+      }
+    }
+    const long wdelta = (long)k0 * (long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-      const int n = n0 + rowb + 32 * i;
-      wr[i] = (kok && n < p.Cout) ? *reinterpret_cast<const uint4*>(wp + (size_t)n * p.Ktot + k0) : make_uint4(0, 0, 0, 0);
+      const bool ok = kok && ((wok >> i) & 1u);
+      glds16(ok ? static_cast<const void*>(wrow[i] + wdelta) : static_cast<const void*>(&g_zero16), sbase + (BM * 8 + i * 256) * 16u);
     }
   };
   auto advance_k = [&]() {
@@ -116,25 +199,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
     while (kc >= p.Cin) { kc -= p.Cin; if (++ks_ == p.ks) { ks_ = 0; ++kr; } }
   };
 
+  const int wm0 = (wave % WM) * (BM / WM), wn0 = (wave / WM) * (BN / WN);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nkt = (p.Ktot + BK - 1) / BK;
+
   f32x4 acc[NJ][MI];
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int wm0 = (wave % WM) * (BM / WM), wn0 = (wave / WM) * (BN / WN);
-  const int fr = lane & 15, fg = lane >> 4;
-  const int nkt = (p.Ktot + BK - 1) / BK;
-
-  issue_loads();
+  issue_loads(0);
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int row = rowb + 32 * i; ldsX[row * 8 + (chunk ^ ((row >> 1) & 7))] = xr[i]; }
-#pragma unroll
-    for (int i = 0; i < WR; ++i) { const int row = rowb + 32 * i; ldsW[row * 8 + (chunk ^ ((row >> 1) & 7))] = wr[i]; }
-    __syncthreads();
-    if (kt + 1 < nkt) { advance_k(); issue_loads(); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of step kt has landed ...
+    __syncthreads();                                   // ... and everyone else's; stage (kt+1)&1 is free again
+    if (kt + 1 < nkt) { advance_k(); issue_loads((kt + 1) & 1); }
+    const uint4* ldsX = lds + (kt & 1) * STAGE;
+    const uint4* ldsW = ldsX + BM * 8;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint4 xf[MI], wf[NJ];
@@ -149,7 +230,47 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
     }
   }
 
-  // ---- epilogue: bias -> activation -> (+residual) -> store 4 consecutive channels of one pixel
+  // ---- epilogue ------------------------------------------------------------------------------------
+  if constexpr (sizeof(T) == 2) {
+    constexpr int ROWB = BN * 2;                       // epilogue tile row (bytes), chunk-swizzled, no padding
+    constexpr int CPR = BN / 8;                        // 16-byte chunks per row
+    if (!p.res && !p.out_f32 && (p.Cout % 8 == 0) && (p.out_coff % 8 == 0) && (p.out_cstride % 8 == 0)) {
+      __syncthreads();                                 // every wave is done reading the K stages
+      char* tilep = reinterpret_cast<char*>(lds);
+      auto to_lds = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int nl = wn0 + j * 16 + fg * 4, n = n0 + nl;
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.bias && n < p.Cout) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const float v0 = activate<T, ACT>(acc[j][i][0] + b4.x), v1 = activate<T, ACT>(acc[j][i][1] + b4.y);
+            const float v2 = activate<T, ACT>(acc[j][i][2] + b4.z), v3 = activate<T, ACT>(acc[j][i][3] + b4.w);
+            const int row = wm0 + i * 16 + fr;
+            const int ch = (nl >> 3) ^ ((row / (16 / CPR)) & (CPR - 1));
+            *reinterpret_cast<uint2*>(tilep + row * ROWB + ch * 16 + (nl & 4) * 2) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
+          }
+        }
+      };
+      if (p.act == 1) to_lds(std::integral_constant<int, 1>{});
+      else if (p.act == 2) to_lds(std::integral_constant<int, 2>{});
+      else to_lds(std::integral_constant<int, 0>{});
+      __syncthreads();
+      T* outp = reinterpret_cast<T*>(p.out) + p.out_coff + n0;
+#pragma unroll
+      for (int q = 0; q < BM * CPR / 256; ++q) {
+        const int idx = tid + 256 * q, row = idx / CPR, ch = idx - row * CPR;
+        const int m = m0 + row;
+        if (m < M && n0 + ch * 8 < p.Cout)
+          *reinterpret_cast<uint4*>(outp + (size_t)m * p.out_cstride + ch * 8) =
+              *reinterpret_cast<const uint4*>(tilep + row * ROWB + (ch ^ ((row / (16 / CPR)) & (CPR - 1))) * 16);
+      }
+      return;
+    }
+  }
+  // direct path: bias -> activation -> (+residual) -> store 4 consecutive channels of one pixel
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int n = n0 + wn0 + j * 16 + fg * 4;
@@ -162,11 +283,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
       if (m >= M) continue;
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = acc[j][i][e] + bv[e];
-        if (p.act == 1) t = act_silu<T>(t); else if (p.act == 2) t = act_gelu_tanh<T>(t);
-        v[e] = t;
-      }
+      for (int e = 0; e < 4; ++e) v[e] = activate_rt<T>(acc[j][i][e] + bv[e], p.act);
       if (p.res) {
         float rv[4];
         const size_t ri = (size_t)m * p.res_cstride + p.res_coff + n;
@@ -187,11 +304,19 @@ template <class T> static bool supported_t(const ConvP& p) {
   if (p.Cin % E || p.Cout % 4 || p.out_coff % 4 || p.out_cstride % 4) return false;
   if (p.res && (p.res_coff % 4 || p.res_cstride % 4)) return false;
   if (p.s0.C + p.s1.C != p.Cin || p.Ktot != p.ks * p.ks * p.Cin) return false;
+  if ((long)p.B * p.Ho * p.Wo >= (1L << 31) || (long)p.Ho * p.Wo >= (1L << 22)) return false;
   return true;
 }
 
 bool conv_mfma_supported(int dt, const ConvP& p) {
   return dt == F32 ? supported_t<float>(p) : supported_t<f16_t>(p);
+}
+
+template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const ConvAux& a, int bn, int ntiles, hipStream_t stream) {
+  const dim3 grid(ntiles), block(256);
+  if (bn == 128) hipLaunchKernelGGL((conv_mfma_kernel<T, 128, 2, SIMPLE>), grid, block, 0, stream, p, a);
+  else if (bn == 64) hipLaunchKernelGGL((conv_mfma_kernel<T, 64, 2, SIMPLE>), grid, block, 0, stream, p, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<T, 32, 4, SIMPLE>), grid, block, 0, stream, p, a);
 }
 
 template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
@@ -201,11 +326,12 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   int bn = 128;
   if (padded(64) < padded(bn)) bn = 64;
   if (padded(32) < padded(bn)) bn = 32;
-  const int nt = (p.Cout + bn - 1) / bn;
-  const dim3 grid(mt * nt), block(256);
-  if (bn == 128) hipLaunchKernelGGL((conv_mfma_kernel<T, 128, 2>), grid, block, 0, stream, p);
-  else if (bn == 64) hipLaunchKernelGGL((conv_mfma_kernel<T, 64, 2>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((conv_mfma_kernel<T, 32, 4>), grid, block, 0, stream, p);
+  ConvAux a{};
+  a.nt = (p.Cout + bn - 1) / bn;
+  a.inv_hw = 1.0f / (float)(p.Ho * p.Wo); a.inv_wo = 1.0f / (float)p.Wo;
+  const bool simple = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
+  a.is1x1 = simple && p.ks == 1 && p.stride == 1 && p.pad == 0 && p.Hin == p.Ho && p.Win == p.Wo;
+  if (simple) launch_ts<T, true>(p, a, bn, mt * a.nt, stream); else launch_ts<T, false>(p, a, bn, mt * a.nt, stream);
   CC_HIP(hipGetLastError());
 }
 
