@@ -19,7 +19,7 @@ namespace {
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 
-struct Lin { void* w = nullptr; float* b = nullptr; int n = 0, k = 0; };   // W[N][K] storage dtype, bias f32
+struct Lin { void* w = nullptr; float* b = nullptr; int n = 0, k = 0, kw = 0; };   // W[N][kw] storage dtype (rows zero padded to 64), bias f32
 struct Norm { float* w = nullptr; float* b = nullptr; };
 struct Block { Norm ln1, ln2; Lin qkv, out, fc, proj; };
 
@@ -83,9 +83,10 @@ Lin make_lin(cc_clip* h, const HostTensor& w, const HostTensor* b, bool transpos
   l.n = transpose ? rest : d0;
   const int k = transpose ? d0 : rest;
   l.k = kpad > k ? kpad : k;
-  std::vector<float> p((size_t)l.n * l.k, 0.f);
+  l.kw = (l.k + 63) / 64 * 64;
+  std::vector<float> p((size_t)l.n * l.kw, 0.f);
   for (int n = 0; n < l.n; ++n)
-    for (int kk = 0; kk < k; ++kk) p[(size_t)n * l.k + kk] = transpose ? w.data[(size_t)kk * l.n + n] : w.data[(size_t)n * k + kk];
+    for (int kk = 0; kk < k; ++kk) p[(size_t)n * l.kw + kk] = transpose ? w.data[(size_t)kk * l.n + n] : w.data[(size_t)n * k + kk];
   std::vector<char> tmp(p.size() * dtype_size(h->dtype));
   convert_f32_to(h->dtype, p.data(), tmp.data(), p.size());
   CC_HIP(hipMalloc(&l.w, tmp.size() + 256));
@@ -109,7 +110,7 @@ Block make_block(cc_clip* h, const std::string& p, const char* out_w, const char
 
 void gemm(CPlan* P, const void* A, int M, const Lin& l, void* out, int out_f32, int act, const void* res) {
   COp op{}; op.kind = 0;
-  op.g = gemm_params(A, l.k, M, l.k, l.w, l.b, l.n, out, l.n, out_f32, act, res, l.n, 1);
+  op.g = gemm_params(A, l.k, M, l.k, l.w, l.kw, l.b, l.n, out, l.n, out_f32, act, res, l.n, 1);
   P->ops.push_back(op);
 }
 void lnorm(CPlan* P, const float* in, long stride, const int* idx, const Norm& n, void* out, int out_f32, int rows, int D) {

@@ -6,13 +6,13 @@
 
 namespace cc {
 
-ConvP gemm_params(const void* A, int lda, int M, int K, const void* W, const float* bias, int N, void* out, int ldc,
+ConvP gemm_params(const void* A, int lda, int M, int K, const void* W, int ldw, const float* bias, int N, void* out, int ldc,
                   int out_f32, int act, const void* res, int ldres, int res_f32) {
   ConvP c{};
   c.s0 = Src{A, 1, M, lda, 0, K, 0};
   c.s1 = Src{A, 1, 1, 0, 0, 0, 0};
   c.B = 1; c.Hin = 1; c.Win = M; c.Cin = K; c.Ho = 1; c.Wo = M; c.Cout = N;
-  c.ks = 1; c.stride = 1; c.pad = 0; c.Ktot = K;
+  c.ks = 1; c.stride = 1; c.pad = 0; c.Ktot = K; c.Kw = ldw;
   c.w = W; c.bias = bias; c.out = out; c.out_cstride = ldc; c.out_coff = 0; c.out_f32 = out_f32;
   c.res = res; c.res_cstride = ldres; c.res_coff = 0; c.res_f32 = res_f32; c.act = act;
   return c;

@@ -97,7 +97,8 @@ struct ConvP {
   int Ho, Wo, Cout;
   int ks, stride, pad;
   int Ktot;                      // ks*ks*Cin
-  const void* w;                 // [Cout][Ktot], storage dtype
+  int Kw;                        // weight row stride in elements (>= Ktot, zero padded to a multiple of 64)
+  const void* w;                 // [Cout][Kw], storage dtype
   const float* bias;             // [Cout] or null
   void* out; int out_cstride, out_coff; int out_f32;
   const void* res; int res_cstride, res_coff; int res_f32;   // optional residual (same pixel grid as out)

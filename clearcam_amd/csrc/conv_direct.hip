@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvP p) {
   const size_t m = idx / p.Cout;
   const int hw = p.Ho * p.Wo;
   const int b = (int)(m / hw), rem = (int)(m - (size_t)b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
-  const T* w = reinterpret_cast<const T*>(p.w) + (size_t)n * p.Ktot;
+  const T* w = reinterpret_cast<const T*>(p.w) + (size_t)n * p.Kw;
   float acc = 0.f;
   for (int r = 0; r < p.ks; ++r) {
     const int ih = ho * p.stride - p.pad + r;

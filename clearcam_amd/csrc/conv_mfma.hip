@@ -14,14 +14,15 @@
 //   16-B chunks of a row are XOR-swizzled by (row>>1)&7.  The DMA writes lane-linear (wave base + lane*16),
 //   so the swizzle is applied to the per-lane SOURCE chunk and again on the fragment read; DMA writes
 //   (8 lanes = one row) and ds_read_b128 (16 rows x one chunk column) are both conflict-free.
-//   Halo / out-of-range lanes read a 16-byte zero page instead of branching.
-// * Instruction diet (rocprofv3 PMC: thin layers were VALU-bound, 2.1k VALU per tile-wave vs 64 MFMA):
-//   per-row base pointers and a 9-bit tap-validity mask are computed once per tile and a K step adds one
-//   per-thread delta (SIMPLE = single source, no upsample); f32->bf16/f16 uses v_cvt_pk_*; the activation
-//   is a compile-time branch of the epilogue.
-// * Epilogue: bias -> activation in registers, then (16-bit outputs) through a consumed LDS stage
-//   (chunk-swizzled) so that every pixel's BN channels leave as 16-byte-per-lane, line-contiguous stores;
-//   f32 outputs / residual adds store directly from registers.
+// * Loader state is one 64-bit pointer per staged row that simply advances by the K step:  cur += inc.
+//   Halo / out-of-range taps point at a 16-byte zero page with inc = 0.  Pointers are re-targeted only when
+//   the thread's chunk crosses into the next filter tap (every Cin/64 steps), from a per-row base pointer and a
+//   9-bit tap-validity mask computed once per tile.  (rocprofv3 PMC showed the first version VALU-bound:
+//   ~170 VALU per K step per wave against 32 MFMA; this form needs ~2 VALU per DMA.)
+// * Weight rows are zero padded to a whole number of K steps at load time, so the K tail needs no checks.
+// * Epilogue: bias -> activation (compile-time branch) in registers, v_cvt_pk to bf16/f16, then (16-bit
+//   outputs) through a consumed LDS stage (chunk-swizzled) so that every pixel's BN channels leave as
+//   16-byte-per-lane, line-contiguous stores; f32 outputs / residual adds store directly from registers.
 // * Tiles are issued in an XCD-aware order (bijective remap of blockIdx): all channel tiles of a pixel tile and
 //   neighbouring pixel tiles run on one XCD's L2.
 // * f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32) with the k-slots of a 16-B chunk spread over 4 MFMAs.
@@ -92,16 +93,31 @@ __device__ __forceinline__ int fdiv(int n, int d, float inv) {
   return q;
 }
 
-// SIMPLE: one source, no upsample, ks <= 3  ->  hoisted row pointers + tap masks.  !SIMPLE: general path.
-template <class T, int BN, int WM, bool SIMPLE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p, const ConvAux a) {
-  constexpr int BM = 128, WN = 4 / WM;
+// CPRW = 16-byte chunks per LDS row: 8 -> 128-byte rows (K step 64 halfs), 4 -> 64-byte rows (K step 32 halfs).
+template <int CPRW> __device__ __forceinline__ int swz(int row) {
+  if constexpr (CPRW == 8) return (row >> 1) & 7;
+  else return (-(row >> 2)) & 3;        // conflict-free for the ds_read_b128 lane groups with 64-byte rows
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// SIMPLE: one source, no upsample, ks <= 3 -> incremental row pointers.  !SIMPLE: general two-source / upsample path.
+// NS = LDS stages: the DMA of step t+NS-1 is issued while step t computes (prefetch distance NS-1 steps).
+// BM = pixels per tile (128 -> 4 waves, 256 -> 8 waves: half the L2->LDS weight traffic per flop).
+template <class T, int BM, int BN, int WM, bool SIMPLE, int CPRW, int NS>
+__global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const ConvAux a) {
+  constexpr int NT = 2 * BM, WN = NT / 64 / WM;
   constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
   constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte chunk
-  constexpr int BK = 8 * E;                // elements per K step (128 bytes)
-  constexpr int WR = BN / 32;              // weight rows staged per thread
-  constexpr int STAGE = (BM + BN) * 8;     // uint4 per stage
-  __shared__ uint4 lds[2 * STAGE];         // the only LDS object (K stages; stage 0 doubles as the epilogue tile)
+  constexpr int BK = CPRW * E;             // elements per K step
+  constexpr int RPP = NT / CPRW;           // rows staged per pass of the NT threads
+  constexpr int XR = BM / RPP;             // pixel rows staged per thread
+  constexpr int WR = BN / RPP;             // weight rows staged per thread
+  constexpr int LPS = XR + WR;             // DMA instructions per thread per K step
+  constexpr int STAGE = (BM + BN) * CPRW;  // uint4 per stage
+  static_assert(BN % RPP == 0, "BN too small for this row width");
+  static_assert(NS * STAGE * 16 >= BM * BN * 2, "epilogue tile must fit in the stages");
+  static_assert(MI >= 1 && NJ >= 1, "bad wave layout");
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // NS stages; the first BM*BN*2 bytes double as the epilogue tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
@@ -117,13 +133,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p, const Con
   const int m0 = mt_ * BM, n0 = (wg - mt_ * a.nt) * BN;
 
   // ---- loader setup: LDS position `ppos` of rows prow + 32*i  <-  global chunk `chunk`
-  const int ppos = tid & 7, prow = tid >> 3;
-  const int chunk = ppos ^ ((prow >> 1) & 7);          // ((prow+32i)>>1)&7 is the same for every i
-  const char* rowp[4]; unsigned vmask[4];              // SIMPLE: byte address of (pixel (h0,w0), channel coff); tap-in-range bits
-  int pb[4], ph0[4], pw0[4];                           // general: batch index, top-left input coordinate
+  const int ppos = tid % CPRW, prow = tid / CPRW;
+  const int chunk = ppos ^ swz<CPRW>(prow);            // swz(prow + RPP*i) is the same for every i
+  const char* rowp[XR]; unsigned vmask[XR];            // SIMPLE: byte address of (pixel (h0,w0), channel coff); tap-in-range bits
+  const char* cur[XR]; unsigned inc[XR];               // SIMPLE: running source pointer and its per-step increment
+  int pb[XR], ph0[XR], pw0[XR];                        // general: batch index, top-left input coordinate
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + prow + 32 * i;
+  for (int i = 0; i < XR; ++i) {
+    const int m = m0 + prow + RPP * i;
     if constexpr (SIMPLE) {
       if (a.is1x1) {
         rowp[i] = reinterpret_cast<const char*>(p.s0.ptr) + ((size_t)m * p.s0.cstride + p.s0.coff) * sizeof(T);
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p, const Con
           hm |= (unsigned)(r < p.ks && (unsigned)(h0 + r) < (unsigned)p.Hin) << r;
           wm |= (unsigned)(r < p.ks && (unsigned)(w0 + r) < (unsigned)p.Win) << r;
         }
-        unsigned vm = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? wm << p.ks : 0u) | ((hm & 4u) ? wm << (2 * p.ks) : 0u);
+        const unsigned vm = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? wm << p.ks : 0u) | ((hm & 4u) ? wm << (2 * p.ks) : 0u);
         vmask[i] = m < M ? vm : 0u;
         rowp[i] = reinterpret_cast<const char*>(p.s0.ptr) +
                   ((((long)b * p.s0.H + h0) * p.s0.W + w0) * (long)p.s0.cstride + p.s0.coff) * (long)sizeof(T);
@@ -150,53 +167,67 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p, const Con
       } else { pb[i] = 0; ph0[i] = -(1 << 28); pw0[i] = 0; }
     }
   }
-  const char* wrow[WR]; unsigned wok = 0;
+  // weight rows: zero padded to whole K steps (p.Kw), rows past Cout read the zero page
+  const char* wcur[WR]; unsigned winc[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
-    const int n = n0 + prow + 32 * i;
-    wrow[i] = reinterpret_cast<const char*>(p.w) + (size_t)n * p.Ktot * sizeof(T);
-    wok |= (n < p.Cout ? 1u : 0u) << i;
+    const int n = n0 + prow + RPP * i;
+    const bool ok = n < p.Cout;
+    wcur[i] = ok ? reinterpret_cast<const char*>(p.w) + ((size_t)n * p.Kw + chunk * E) * sizeof(T) : reinterpret_cast<const char*>(&g_zero16);
+    winc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
   }
   int k0 = chunk * E, kc, kr, ks_;                     // this thread's k index; its channel, tap row, tap col
   if (k0 < p.Cin) { kc = k0; kr = 0; ks_ = 0; }
   else { const int tap = k0 / p.Cin; kc = k0 - tap * p.Cin; kr = tap / p.ks; ks_ = tap - kr * p.ks; }
 
+  auto retarget = [&]() {                              // SIMPLE: (kr, ks_, kc) changed tap -> new pointers
+    const bool kok = kr < p.ks;                        // k0 < Ktot
+    const int tbit = kr * p.ks + ks_;
+    const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc) * (long)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const bool ok = kok && ((vmask[i] >> tbit) & 1u);
+      cur[i] = ok ? rowp[i] + delta : reinterpret_cast<const char*>(&g_zero16);
+      inc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
+    }
+  };
+  if constexpr (SIMPLE) retarget();
+
   auto issue_loads = [&](int stage) {
-    const bool kok = k0 < p.Ktot;
     // wave-uniform LDS byte address of this wave's 1 KiB slice of the stage (+ lane*16 added by the DMA)
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE + wave * 64) * 16u);
     if constexpr (SIMPLE) {
-      const int tbit = kr * p.ks + ks_;
-      const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc) * (long)sizeof(T);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = kok && ((vmask[i] >> tbit) & 1u);
-        glds16(ok ? static_cast<const void*>(rowp[i] + delta) : static_cast<const void*>(&g_zero16), sbase + i * 4096u);
-      }
+      for (int i = 0; i < XR; ++i) glds16(cur[i], sbase + i * (NT * 16u));
     } else {
+      const bool kok = k0 < p.Ktot;
       const bool first = kc < p.s0.C;
       const T* sp = reinterpret_cast<const T*>(first ? p.s0.ptr : p.s1.ptr);
       const int scs = first ? p.s0.cstride : p.s1.cstride, sco = first ? p.s0.coff : p.s1.coff;
       const int cc = first ? kc : kc - p.s0.C;
       const int sH = first ? p.s0.H : p.s1.H, sW = first ? p.s0.W : p.s1.W, ssh = first ? p.s0.shift : p.s1.shift;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < XR; ++i) {
         const int ih = ph0[i] + kr, iw = pw0[i] + ks_;
         const bool ok = kok && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
         const size_t off = ((size_t)(pb[i] * sH + (ih >> ssh)) * sW + (iw >> ssh)) * scs + sco + cc;
-        glds16(ok ? static_cast<const void*>(sp + off) : static_cast<const void*>(&g_zero16), sbase + i * 4096u);
+        glds16(ok ? static_cast<const void*>(sp + off) : static_cast<const void*>(&g_zero16), sbase + i * (NT * 16u));
       }
     }
-    const long wdelta = (long)k0 * (long)sizeof(T);
 #pragma unroll
-    for (int i = 0; i < WR; ++i) {
-      const bool ok = kok && ((wok >> i) & 1u);
-      glds16(ok ? static_cast<const void*>(wrow[i] + wdelta) : static_cast<const void*>(&g_zero16), sbase + (BM * 8 + i * 256) * 16u);
-    }
+    for (int i = 0; i < WR; ++i) glds16(wcur[i], sbase + (BM * CPRW + i * NT) * 16u);
   };
   auto advance_k = [&]() {
     k0 += BK; kc += BK;
-    while (kc >= p.Cin) { kc -= p.Cin; if (++ks_ == p.ks) { ks_ = 0; ++kr; } }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) wcur[i] += winc[i];
+    if (kc >= p.Cin) {
+      do { kc -= p.Cin; if (++ks_ == p.ks) { ks_ = 0; ++kr; } } while (kc >= p.Cin);
+      if constexpr (SIMPLE) retarget();
+    } else if constexpr (SIMPLE) {
+#pragma unroll
+      for (int i = 0; i < XR; ++i) cur[i] += inc[i];
+    }
   };
 
   const int wm0 = (wave % WM) * (BM / WM), wn0 = (wave / WM) * (BN / WN);
@@ -209,20 +240,30 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p, const Con
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue_loads(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of step kt has landed ...
-    __syncthreads();                                   // ... and everyone else's; stage (kt+1)&1 is free again
-    if (kt + 1 < nkt) { advance_k(); issue_loads((kt + 1) & 1); }
-    const uint4* ldsX = lds + (kt & 1) * STAGE;
-    const uint4* ldsW = ldsX + BM * 8;
+  // prologue: steps 0 .. NS-2 in flight
+  int issued = 0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) { if (s > 0) advance_k(); issue_loads(s); ++issued; }
+  int st_c = 0, st_i = NS - 1;                          // stage being consumed / stage the next DMA goes to
+  for (int kt = 0; kt < nkt; ++kt) {
+    // step kt must have landed; later steps (at most NS-2 of them) may stay in flight
+    const int ahead = issued - kt - 1;
+    if (NS > 3 && ahead >= 2) wait_vmcnt<2 * LPS>();
+    else if (NS > 2 && ahead >= 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __syncthreads();                                   // ... for every wave; the stage consumed at step kt-1 is free again
+    if (issued < nkt) { advance_k(); issue_loads(st_i); ++issued; if (++st_i == NS) st_i = 0; }
+    const uint4* ldsX = lds + st_c * STAGE;
+    const uint4* ldsW = ldsX + BM * CPRW;
+    if (++st_c == NS) st_c = 0;
+#pragma unroll
+    for (int h = 0; h < CPRW / 4; ++h) {
       uint4 xf[MI], wf[NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) { const int row = wm0 + i * 16 + fr; xf[i] = ldsX[row * 8 + ((h * 4 + fg) ^ ((row >> 1) & 7))]; }
+      for (int i = 0; i < MI; ++i) { const int row = wm0 + i * 16 + fr; xf[i] = ldsX[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) { const int row = wn0 + j * 16 + fr; wf[j] = ldsW[row * 8 + ((h * 4 + fg) ^ ((row >> 1) & 7))]; }
+      for (int j = 0; j < NJ; ++j) { const int row = wn0 + j * 16 + fr; wf[j] = ldsW[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -260,8 +301,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p, const Con
       __syncthreads();
       T* outp = reinterpret_cast<T*>(p.out) + p.out_coff + n0;
 #pragma unroll
-      for (int q = 0; q < BM * CPR / 256; ++q) {
-        const int idx = tid + 256 * q, row = idx / CPR, ch = idx - row * CPR;
+      for (int q = 0; q < BM * CPR / NT; ++q) {
+        const int idx = tid + NT * q, row = idx / CPR, ch = idx - row * CPR;
         const int m = m0 + row;
         if (m < M && n0 + ch * 8 < p.Cout)
           *reinterpret_cast<uint4*>(outp + (size_t)m * p.out_cstride + ch * 8) =
@@ -304,6 +345,7 @@ template <class T> static bool supported_t(const ConvP& p) {
   if (p.Cin % E || p.Cout % 4 || p.out_coff % 4 || p.out_cstride % 4) return false;
   if (p.res && (p.res_coff % 4 || p.res_cstride % 4)) return false;
   if (p.s0.C + p.s1.C != p.Cin || p.Ktot != p.ks * p.ks * p.Cin) return false;
+  if (p.Kw < (p.Ktot + 8 * E - 1) / (8 * E) * (8 * E)) return false;      // weight rows must cover whole K steps
   if ((long)p.B * p.Ho * p.Wo >= (1L << 31) || (long)p.Ho * p.Wo >= (1L << 22)) return false;
   return true;
 }
@@ -312,16 +354,45 @@ bool conv_mfma_supported(int dt, const ConvP& p) {
   return dt == F32 ? supported_t<float>(p) : supported_t<f16_t>(p);
 }
 
-template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const ConvAux& a, int bn, int ntiles, hipStream_t stream) {
-  const dim3 grid(ntiles), block(256);
-  if (bn == 128) hipLaunchKernelGGL((conv_mfma_kernel<T, 128, 2, SIMPLE>), grid, block, 0, stream, p, a);
-  else if (bn == 64) hipLaunchKernelGGL((conv_mfma_kernel<T, 64, 2, SIMPLE>), grid, block, 0, stream, p, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<T, 32, 4, SIMPLE>), grid, block, 0, stream, p, a);
+// Tile configuration per channel-tile width, tunable with CLEARCAM_CONV_CFG="bm128,ns128,bm64,ns64"
+// (bm: 128|256 pixels per tile, ns: 2|3 stages).
+static int g_cfg[4] = {-1, 0, 0, 0};
+
+template <class T, int BM, int BN, int WM, bool SIMPLE, int CPRW, int NS>
+static void launch_k(const ConvP& p, const ConvAux& a, int mtiles, hipStream_t stream) {
+  constexpr size_t lds = (size_t)NS * (BM + BN) * CPRW * 16;
+  static bool configured = false;
+  if (!configured) {
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>), dim3(mtiles * a.nt), dim3(2 * BM), lds, stream, p, a);
+}
+
+template <class T, int BN, bool SIMPLE>
+static void launch_cfg(const ConvP& p, const ConvAux& a, int M, int bm, int ns, hipStream_t stream) {
+  if (bm == 256) {
+    const int mt = (M + 255) / 256;
+    if (ns == 3) launch_k<T, 256, BN, 4, SIMPLE, 8, 3>(p, a, mt, stream); else launch_k<T, 256, BN, 4, SIMPLE, 8, 2>(p, a, mt, stream);
+  } else {
+    const int mt = (M + 127) / 128;
+    if (ns == 3) launch_k<T, 128, BN, 2, SIMPLE, 8, 3>(p, a, mt, stream); else launch_k<T, 128, BN, 2, SIMPLE, 8, 2>(p, a, mt, stream);
+  }
+}
+
+template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const ConvAux& a, int bn, int M, hipStream_t stream) {
+  if (g_cfg[0] < 0) {
+    g_cfg[0] = 128; g_cfg[1] = 2; g_cfg[2] = 128; g_cfg[3] = 2;
+    if (const char* e = getenv("CLEARCAM_CONV_CFG")) sscanf(e, "%d,%d,%d,%d", &g_cfg[0], &g_cfg[1], &g_cfg[2], &g_cfg[3]);
+  }
+  if (bn == 128) launch_cfg<T, 128, SIMPLE>(p, a, M, g_cfg[0], g_cfg[1], stream);
+  else if (bn == 64) launch_cfg<T, 64, SIMPLE>(p, a, M, g_cfg[2], g_cfg[3], stream);
+  else launch_k<T, 128, 32, 4, SIMPLE, 8, 2>(p, a, (M + 127) / 128, stream);
 }
 
 template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   const int M = p.B * p.Ho * p.Wo;
-  const int mt = (M + 127) / 128;
   auto padded = [&](int bn) { return (p.Cout + bn - 1) / bn * bn; };
   int bn = 128;
   if (padded(64) < padded(bn)) bn = 64;
@@ -331,7 +402,7 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   a.inv_hw = 1.0f / (float)(p.Ho * p.Wo); a.inv_wo = 1.0f / (float)p.Wo;
   const bool simple = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
   a.is1x1 = simple && p.ks == 1 && p.stride == 1 && p.pad == 0 && p.Hin == p.Ho && p.Win == p.Wo;
-  if (simple) launch_ts<T, true>(p, a, bn, mt * a.nt, stream); else launch_ts<T, false>(p, a, bn, mt * a.nt, stream);
+  if (simple) launch_ts<T, true>(p, a, bn, M, stream); else launch_ts<T, false>(p, a, bn, M, stream);
   CC_HIP(hipGetLastError());
 }
 

@@ -54,7 +54,7 @@ void launch_topk_nms(const NmsP& p, hipStream_t stream);
 
 // ---- CLIP towers (clip_kernels.hip) -------------------------------------------------------------
 // Plain GEMM through the conv kernel:  out[M][N] = act(A[M][K] W[N][K]^T + bias) (+res).
-ConvP gemm_params(const void* A, int lda, int M, int K, const void* W, const float* bias, int N, void* out, int ldc,
+ConvP gemm_params(const void* A, int lda, int M, int K, const void* W, int ldw, const float* bias, int N, void* out, int ldc,
                   int out_f32, int act, const void* res, int ldres, int res_f32);
 
 struct LnP {                  // LayerNorm(eps 1e-5, biased var, affine): models/objects.py:105,123,129,153,176,182

@@ -36,7 +36,7 @@ static const Arch kArch[] = {
 };
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
-struct PackedConv { void* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 0; double macs_px = 0; };
+struct PackedConv { void* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 0, kw = 0; double macs_px = 0; };
 
 struct Buf { int H, W, C; bool f32; size_t off; };
 struct View { int buf; int coff; int C; };
@@ -108,7 +108,8 @@ static PackedConv pack_convs(int dt, const std::vector<const HostTensor*>& ws, c
     cin = ci; cout += (int)ws[t]->shape[0];
   }
   const int cp = cin_pad > cin ? cin_pad : cin;
-  const size_t ktot = (size_t)k * k * cp;
+  const size_t kreal = (size_t)k * k * cp;
+  const size_t ktot = (kreal + 63) / 64 * 64;          // row stride: zero padded to a whole number of K steps
   std::vector<float> w((size_t)cout * ktot, 0.f), bias(cout, 0.f);
   int n0 = 0;
   for (size_t t = 0; t < ws.size(); ++t) {
@@ -126,11 +127,11 @@ static PackedConv pack_convs(int dt, const std::vector<const HostTensor*>& ws, c
   }
   std::vector<char> tmp(w.size() * dtype_size(dt));
   convert_f32_to(dt, w.data(), tmp.data(), w.size());
-  CC_HIP(hipMalloc(&pc.w, tmp.size()));
+  CC_HIP(hipMalloc(&pc.w, tmp.size() + 256));
   CC_HIP(hipMemcpy(pc.w, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
   CC_HIP(hipMalloc((void**)&pc.bias, cout * 4));
   CC_HIP(hipMemcpy(pc.bias, bias.data(), cout * 4, hipMemcpyHostToDevice));
-  pc.cin = cp; pc.cout = cout; pc.k = k;
+  pc.cin = cp; pc.cout = cout; pc.k = k; pc.kw = (int)ktot;
   return pc;
 }
 
@@ -187,7 +188,7 @@ struct Builder {
     c.Ho = (c.Hin + 2 * c.pad - c.ks) / stride + 1; c.Wo = (c.Win + 2 * c.pad - c.ks) / stride + 1;
     const Buf& ob = P->bufs[out.buf];
     CC_CHECK(ob.H == c.Ho && ob.W == c.Wo && out.C == pc.cout, "conv output view mismatch");
-    c.Cout = pc.cout; c.Ktot = c.ks * c.ks * c.Cin;
+    c.Cout = pc.cout; c.Ktot = c.ks * c.ks * c.Cin; c.Kw = pc.kw;
     c.w = pc.w; c.bias = pc.bias;
     c.out = (void*)(intptr_t)out.buf; c.out_cstride = ob.C; c.out_coff = out.coff; c.out_f32 = ob.f32;
     if (res) { const Buf& rb = P->bufs[res->buf]; c.res = (const void*)(intptr_t)res->buf; c.res_cstride = rb.C; c.res_coff = res->coff; c.res_f32 = rb.f32; }
@@ -649,7 +650,7 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
   ConvP c{};
   c.s0 = Src{x_dev, H, W, Cin, 0, Cin, 0}; c.s1 = Src{x_dev, 1, 1, 0, 0, 0, 0};
   c.B = B; c.Hin = H; c.Win = W; c.Cin = Cin; c.ks = k; c.stride = stride; c.pad = k / 2;
-  c.Ho = (H + 2 * c.pad - k) / stride + 1; c.Wo = (W + 2 * c.pad - k) / stride + 1; c.Cout = Cout; c.Ktot = k * k * Cin;
+  c.Ho = (H + 2 * c.pad - k) / stride + 1; c.Wo = (W + 2 * c.pad - k) / stride + 1; c.Cout = Cout; c.Ktot = k * k * Cin; c.Kw = pc.kw;
   c.w = pc.w; c.bias = pc.bias; c.out = out_dev; c.out_cstride = Cout; c.out_coff = 0; c.out_f32 = 0; c.res = nullptr; c.act = act;
   if (force_direct) launch_conv_direct(dtype, c, (hipStream_t)stream); else launch_conv(dtype, c, (hipStream_t)stream);
   CC_HIP(hipStreamSynchronize((hipStream_t)stream));
