@@ -58,6 +58,63 @@ def cpu_baseline(size: str, res: int, seconds: float = 15.0) -> dict:
                       f"of detection/yolov9.py (tinygrad CPU path not runnable offline)"}
 
 
+def clip_side_metrics(device_index: int, dev) -> dict:
+    """Second half of BASELINE.json's metric: CLIP ViT-L/14 image embeds/s (configs[2]) and the search scan
+    (configs[4], one GPU's shard).  Same rules: seeded synthetic weights, inputs resident in HBM, hipEvent/sync timing."""
+    import torch
+    from clearcam_amd.arch import CLIP_L14
+    from clearcam_amd.objects import EmbeddingIndex, OpenCLIP
+    from clearcam_amd.weights import synthetic_clip_state_dict
+    out = {}
+    m = OpenCLIP(state_dict=synthetic_clip_state_dict(CLIP_L14, 4321), arch=CLIP_L14, dtype="bf16", device=device_index)
+    B = 256
+    x = torch.rand(B, 3, 224, 224, device=dev) * 2 - 1
+    emb = torch.empty(B, 768, device=dev)
+    for _ in range(2):
+        m.precompute_embedding_device(x, emb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 4
+    for _ in range(n):
+        m.precompute_embedding_device(x, emb)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out["image_embeds_per_sec"] = round(B / dt, 1)
+    out["image_batch"] = B
+    out["image_tflops"] = round(B * 162.03e9 / dt / 1e12, 1)
+    out["seconds_per_10k_crops"] = round(10000 / (B / dt), 3)
+    toks = np.zeros((64, 77), np.int32)
+    toks[:, 0] = 49406
+    toks[:, 1:5] = [9606, 325, 275, 271]
+    toks[:, 5] = 49407
+    m.encode_tokens(toks)
+    t0 = time.perf_counter()
+    m.encode_tokens(toks)
+    out["text_embeds_per_sec"] = round(64 / (time.perf_counter() - t0), 1)
+    m.close()
+    # search: 125k x 768 f32 shard (1 M vectors over 8 GPUs), k=100, 1 query; HBM-bound scan of 384 MB
+    N = 125_000
+    ix = EmbeddingIndex(768, N, device=device_index)
+    e = torch.randn(N, 768, device=dev)
+    e /= e.norm(dim=1, keepdim=True)
+    ix.add(e)
+    q = torch.randn(1, 768)
+    q /= q.norm()
+    qn = q.numpy()
+    for _ in range(3):
+        ix.search(qn, 100)
+    lat = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        ix.search(qn, 100)
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
+    out["search_125k_k100_p50_ms"] = round(lat[len(lat) // 2] * 1e3, 3)
+    out["search_scan_GBps"] = round(N * 768 * 4 / lat[len(lat) // 2] / 1e9, 1)
+    ix.close()
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +125,7 @@ def main() -> None:
     ap.add_argument("--res", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clip", action="store_true", help="skip the CLIP / search side metrics")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +197,9 @@ def main() -> None:
                          "other_ms_per_step": {k: round(prof[k], 3) for k in ("pool_ms", "decode_ms", "nms_ms")}},
             "gflop_per_frame": round(alg_flops / B / 1e9, 2),
         }
+        if not args.no_clip:
+            model.close()
+            line["clip"] = clip_side_metrics(local, dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.size, args.res)
         print(json.dumps(line), flush=True)

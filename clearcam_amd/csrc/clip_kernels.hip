@@ -169,10 +169,11 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnP p) {
   uint4* ldsK = reinterpret_cast<uint4*>(smem);                         // [LP][8 chunks]
   T* ldsVt = reinterpret_cast<T*>(smem + (size_t)LP * 128);             // [64][VS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+  const int b = blockIdx.z, h = blockIdx.y;
   const int D3 = 3 * p.D;
   const T* base = reinterpret_cast<const T*>(p.qkv) + (size_t)b * p.L * D3 + h * 64;
 
+  // stage K and V^T of this (image, head) ONCE; the workgroup then walks all 64-query tiles
   for (int idx = tid; idx < LP * 8; idx += 256) {
     const int key = idx >> 3, chunk = idx & 7;
     uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
@@ -187,68 +188,71 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnP p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ldsVt[(chunk * 8 + e) * VS + pos] = ve[e];
   }
-  const int ql = lane & 15, g = lane >> 4, q = q0 + ql;
-  uint4 qf[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-    qf[ks] = q < p.L ? *reinterpret_cast<const uint4*>(base + (size_t)q * D3 + (ks * 4 + g) * 8) : make_uint4(0, 0, 0, 0);
   __syncthreads();
+  const int ql = lane & 15, g = lane >> 4;
+  for (int q0 = wave * 16; q0 < p.L; q0 += 64) {
+    const int q = q0 + ql;
+    uint4 qf[2];
+  #pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = q < p.L ? *reinterpret_cast<const uint4*>(base + (size_t)q * D3 + (ks * 4 + g) * 8) : make_uint4(0, 0, 0, 0);
 
-  f32x4 s[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int row = f * 16 + ql;
-      Mma<T>::run(ldsK[row * 8 + ((ks * 4 + g) ^ ((row >> 1) & 7))], qf[ks], s[f]);
+    f32x4 s[NF];
+  #pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int row = f * 16 + ql;
+        Mma<T>::run(ldsK[row * 8 + ((ks * 4 + g) ^ ((row >> 1) & 7))], qf[ks], s[f]);
+      }
     }
-  }
-  // s[f][r] = <k_{16f+4g+r}, q_{ql}>
-  float mx = -INFINITY;
-#pragma unroll
-  for (int f = 0; f < NF; ++f)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = f * 16 + g * 4 + r;
-      float v = s[f][r] * p.scale;
-      if (key >= p.L || (p.causal && key > q)) v = -INFINITY;
-      s[f][r] = v;
-      mx = fmaxf(mx, v);
-    }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float sum = 0.f;
-#pragma unroll
-  for (int f = 0; f < NF; ++f)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const float e = __expf(s[f][r] - mx); s[f][r] = e; sum += e; }
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
+    // s[f][r] = <k_{16f+4g+r}, q_{ql}>
+    float mx = -INFINITY;
+  #pragma unroll
+    for (int f = 0; f < NF; ++f)
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = f * 16 + g * 4 + r;
+        float v = s[f][r] * p.scale;
+        if (key >= p.L || (p.causal && key > q)) v = -INFINITY;
+        s[f][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+  #pragma unroll
+    for (int f = 0; f < NF; ++f)
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = __expf(s[f][r] - mx); s[f][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
 
-  f32x4 o[4];
-#pragma unroll
-  for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int f2 = 0; f2 < NF / 2; ++f2) {
-    // B operand k-slot (g, j): j<4 -> key 32f2 + 4g + j, j>=4 -> key 32f2 + 16 + 4g + (j-4); V^T was staged in that order
-    alignas(16) T pk[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pk[r] = from_f32<T>(s[2 * f2][r]); pk[4 + r] = from_f32<T>(s[2 * f2 + 1][r]); }
-    const uint4 pf = *reinterpret_cast<const uint4*>(pk);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const uint4 vf = *reinterpret_cast<const uint4*>(ldsVt + (d * 16 + ql) * VS + f2 * 32 + g * 8);
-      Mma<T>::run(vf, pf, o[d]);
+    f32x4 o[4];
+  #pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+    for (int f2 = 0; f2 < NF / 2; ++f2) {
+      // B operand k-slot (g, j): j<4 -> key 32f2 + 4g + j, j>=4 -> key 32f2 + 16 + 4g + (j-4); V^T was staged in that order
+      alignas(16) T pk[8];
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) { pk[r] = from_f32<T>(s[2 * f2][r]); pk[4 + r] = from_f32<T>(s[2 * f2 + 1][r]); }
+      const uint4 pf = *reinterpret_cast<const uint4*>(pk);
+  #pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(ldsVt + (d * 16 + ql) * VS + f2 * 32 + g * 8);
+        Mma<T>::run(vf, pf, o[d]);
+      }
     }
-  }
-  if (q < p.L) {
-    const float inv = 1.0f / sum;
-    T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q) * p.D + h * 64;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      alignas(8) T t4[4] = {from_f32<T>(o[d][0] * inv), from_f32<T>(o[d][1] * inv), from_f32<T>(o[d][2] * inv), from_f32<T>(o[d][3] * inv)};
-      *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = *reinterpret_cast<uint2*>(t4);
+    if (q < p.L) {
+      const float inv = 1.0f / sum;
+      T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q) * p.D + h * 64;
+  #pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        alignas(8) T t4[4] = {from_f32<T>(o[d][0] * inv), from_f32<T>(o[d][1] * inv), from_f32<T>(o[d][2] * inv), from_f32<T>(o[d][3] * inv)};
+        *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = *reinterpret_cast<uint2*>(t4);
+      }
     }
   }
 }
@@ -295,7 +299,7 @@ template <class T, int NF> static void launch_attn_mfma(const AttnP& p, hipStrea
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<T, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
-  hipLaunchKernelGGL((attn_mfma_kernel<T, NF>), dim3((p.L + 63) / 64, p.H, p.B), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((attn_mfma_kernel<T, NF>), dim3(1, p.H, p.B), dim3(256), lds, stream, p);
 }
 
 void launch_attention(int dt, const AttnP& p, hipStream_t stream) {

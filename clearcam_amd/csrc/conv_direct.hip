@@ -138,6 +138,48 @@ template <class T> static void launch_pool_t(const PoolP& p, hipStream_t stream)
   CC_HIP(hipGetLastError());
 }
 
+// ---- CBFuse: sum of nearest-upsampled channel slices, 16 bytes of channels per thread ----------------
+template <class T>
+__global__ __launch_bounds__(256) void fuse_kernel(const FuseP p) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int CV = p.C / E;
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * CV;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % CV);
+  const size_t m = idx / CV;
+  const int hw = p.Ho * p.Wo;
+  const int b = (int)(m / hw), rem = (int)(m - (size_t)b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  for (int k = 0; k < p.n; ++k) {
+    const T* in = reinterpret_cast<const T*>(p.in[k]) +
+                  ((size_t)(b * p.H[k] + (ho >> p.shift[k])) * p.W[k] + (wo >> p.shift[k])) * p.cstride[k] + p.coff[k] + cv * E;
+    const uint4 u = *reinterpret_cast<const uint4*>(in);
+    const T* t = reinterpret_cast<const T*>(&u);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] += to_f32<T>(t[e]);
+  }
+  uint4 o;
+  T* t = reinterpret_cast<T*>(&o);
+#pragma unroll
+  for (int e = 0; e < E; ++e) t[e] = from_f32<T>(acc[e]);
+  *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
+}
+
+void launch_fuse(int dt, const FuseP& p, hipStream_t stream) {
+  const int E = dt == F32 ? 4 : 8;
+  CC_CHECK(p.C % E == 0 && p.out_coff % E == 0 && p.out_cstride % E == 0, "fuse: channel alignment");
+  for (int k = 0; k < p.n; ++k) CC_CHECK(p.coff[k] % E == 0 && p.cstride[k] % E == 0, "fuse: input channel alignment");
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * (p.C / E);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dt == F32) hipLaunchKernelGGL(fuse_kernel<float>, grid, block, 0, stream, p);
+  else if (dt == F16) hipLaunchKernelGGL(fuse_kernel<f16_t>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(fuse_kernel<bf16_t>, grid, block, 0, stream, p);
+  CC_HIP(hipGetLastError());
+}
+
 void launch_pool(int dt, const PoolP& p, hipStream_t stream) {
   if (dt == F32) launch_pool_t<float>(p, stream);
   else if (dt == F16) launch_pool_t<f16_t>(p, stream);

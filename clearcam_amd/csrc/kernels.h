@@ -24,6 +24,15 @@ struct PoolP {
 };
 void launch_pool(int dt, const PoolP& p, hipStream_t stream);
 
+// CBFuse (detection/yolov9.py:230-245): out = sum_k nearest_upsample(in_k, 2^shift_k) (+ the last, unscaled input)
+struct FuseP {
+  int n;                                  // inputs (<= 6)
+  const void* in[6]; int H[6], W[6], cstride[6], coff[6], shift[6];
+  void* out; int out_cstride, out_coff;
+  int B, Ho, Wo, C;
+};
+void launch_fuse(int dt, const FuseP& p, hipStream_t stream);
+
 // ---- detector pre/post (detect.hip) ------------------------------------------------------------
 struct PreP {                 // letterbox: detection/yolov9.py:376-379,390-404
   const void* frames; int frame_f32;      // (B,H,W,3) BGR u8 or f32

@@ -33,6 +33,8 @@ static const Arch kArch[] = {
     {"s", 32, true, 64, 64, false, 128, 32, 128, 128, 192, 48, 192, 256, 64, 256, 128, 96, 128, 128, 3},
     {"m", 32, false, 32, 128, false, 240, 60, 240, 240, 360, 90, 360, 480, 120, 480, 240, 184, 240, 240, 1},
     {"c", 64, false, 32, 256, true, 256, 64, 256, 512, 512, 128, 512, 512, 128, 512, 256, 256, 512, 256, 1},
+    // "e" (yolov9.py:328-371) has its own 43-block builder; only adown / cls_hidden / rep_n are read from this row
+    {"e", 64, false, 32, 256, true, 0, 0, 256, 0, 0, 0, 512, 0, 0, 512, 256, 0, 0, 256, 2},
 };
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
@@ -43,8 +45,8 @@ struct View { int buf; int coff; int C; };
 struct In { View v; int shift; };
 
 struct Op {
-  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms
-  ConvP conv; PoolP pool; DecodeP dec; NmsP nms;
+  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms, 4 fuse
+  ConvP conv; PoolP pool; DecodeP dec; NmsP nms; FuseP fuse;
   double alg_macs = 0;   // algorithmic multiply-accumulates of this launch (no padding / densification)
 };
 
@@ -275,7 +277,105 @@ struct Builder {
     return whole(o);
   }
 
+  // CBLinear (:222-228): bare 1x1 conv; the split is a set of channel-offset views of its output
+  View cblinear(const std::string& p, View in) {
+    const PackedConv& pc = pconv({p + ".conv"}, {1});
+    const int o = new_buf(P->bufs[in.buf].H, P->bufs[in.buf].W, pc.cout);
+    conv({{in, 0}}, pc, whole(o), 1, 0);
+    return whole(o);
+  }
+  // CBFuse (:230-245): parts are nearest-upsampled to `last`'s size and summed with it
+  View cbfuse(const std::vector<View>& parts, View last) {
+    const Buf& lb = P->bufs[last.buf];
+    const int o = new_buf(lb.H, lb.W, last.C);
+    Op op{}; op.kind = 4; FuseP& f = op.fuse;
+    f.n = (int)parts.size() + 1; CC_CHECK(f.n <= 6, "CBFuse: too many inputs");
+    for (int k = 0; k < f.n; ++k) {
+      const View& v = k + 1 < f.n ? parts[k] : last;
+      const Buf& b = P->bufs[v.buf];
+      CC_CHECK(v.C == last.C && lb.H % b.H == 0, "CBFuse input mismatch");
+      int sh = 0; while ((b.H << sh) < lb.H) ++sh;
+      CC_CHECK((b.H << sh) == lb.H && (b.W << sh) == lb.W, "CBFuse scale must be a power of two");
+      f.in[k] = (const void*)(intptr_t)v.buf; f.H[k] = b.H; f.W[k] = b.W; f.cstride[k] = b.C; f.coff[k] = v.coff; f.shift[k] = sh;
+    }
+    f.out = (void*)(intptr_t)o; f.out_cstride = last.C; f.out_coff = 0; f.B = P->B; f.Ho = lb.H; f.Wo = lb.W; f.C = last.C;
+    P->ops.push_back(op);
+    return whole(o);
+  }
+
+  void head(const std::string& H22, const View (&feats)[3]) {
+    Op dec{}; dec.kind = 2;
+    P->A = 0;
+    for (int l = 0; l < 3; ++l) {
+      const std::string hb = H22 + "cv2.list." + std::to_string(l) + ".list.", hc = H22 + "cv3.list." + std::to_string(l) + ".list.";
+      const int H = P->bufs[feats[l].buf].H, W = P->bufs[feats[l].buf].W, ch = a.cls_hidden;
+      const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch), raw = new_buf(H, W, 144, true);
+      conv({{feats[l], 0}}, pconv({hb + "0.conv", hc + "0.conv"}, {1, 1}), whole(hbuf), 1, 1);
+      conv({{slice(whole(hbuf), 0, 64), 0}}, pconv({hb + "1.conv"}, {4}), whole(bxb), 1, 1);
+      conv({{slice(whole(hbuf), 64, ch), 0}}, pconv({hc + "1.conv"}, {1}), whole(clb), 1, 1);
+      conv({{whole(bxb), 0}}, pconv({hb + "2"}, {4}), slice(whole(raw), 0, 64), 1, 0);
+      conv({{whole(clb), 0}}, pconv({hc + "2"}, {1}), slice(whole(raw), 64, 80), 1, 0);
+      P->taps["raw" + std::to_string(l)] = raw;
+      dec.dec.raw[l] = (const float*)(intptr_t)raw; dec.dec.H[l] = H; dec.dec.W[l] = W;
+      P->A += H * W;
+    }
+    dec.dec.B = P->B; dec.dec.A = P->A; dec.dec.dfl_w = Y->dfl_w; dec.dec.conf = 0.25f;
+    P->ops.push_back(dec);
+    Op nms{}; nms.kind = 3;
+    nms.nms.B = P->B; nms.nms.A = P->A; nms.nms.iou_thr = 0.45f;
+    // scale_boxes (:406-416): python-float arithmetic, then f32 tensor ops
+    const double gain = std::min((double)P->Hn / P->H, (double)P->Wn / P->W);
+    nms.nms.gain = (float)gain;
+    nms.nms.pad_x = (float)((P->Wn - P->W * gain) / 2); nms.nms.pad_y = (float)((P->Hn - P->H * gain) / 2);
+    nms.nms.src_w = (float)P->W; nms.nms.src_h = (float)P->H;
+    P->ops.push_back(nms);
+  }
+
+  void build_e() {   // detection/yolov9.py:328-371
+    const std::string M = "model.list.";
+    const int cp = Y->cin_pad();
+    P->in_buf = new_buf(P->Hn, P->Wn, cp);
+    P->taps["input"] = P->in_buf;
+    auto stem = [&](const std::string& n, View in, int cout, int cpad) {
+      const Buf& b = P->bufs[in.buf];
+      const int o = new_buf(b.H / 2, b.W / 2, cout);
+      conv({{in, 0}}, pconv({n + ".conv"}, {1}, cpad), whole(o), 2, 1);
+      return whole(o);
+    };
+    const View y1 = stem(M + "1", whole(P->in_buf), 64, cp), y2 = stem(M + "2", y1, 128, 0);
+    const View y3 = elan4(M + "3", {{y2, 0}}, 32, 256), y4 = down(M + "4", y3, 256);
+    const View y5 = elan4(M + "5", {{y4, 0}}, 64, 512), y6 = down(M + "6", y5, 512);
+    const View y7 = elan4(M + "7", {{y6, 0}}, 128, 1024), y8 = down(M + "8", y7, 1024);
+    const View y9 = elan4(M + "9", {{y8, 0}}, 128, 1024);
+    const View c10 = cblinear(M + "10", y1), c11 = cblinear(M + "11", y3), c12 = cblinear(M + "12", y5),
+               c13 = cblinear(M + "13", y7), c14 = cblinear(M + "14", y9);
+    // split offsets: [64 | 128 | 256 | 512 | 1024]
+    auto part = [&](View c, int idx) { static const int off[5] = {0, 64, 192, 448, 960}; return slice(c, off[idx], 64 << idx); };
+    const View y15 = stem(M + "15", whole(P->in_buf), 64, cp);
+    const View y16 = cbfuse({part(c10, 0), part(c11, 0), part(c12, 0), part(c13, 0), part(c14, 0)}, y15);
+    const View y17 = stem(M + "17", y16, 128, 0);
+    const View y18 = cbfuse({part(c11, 1), part(c12, 1), part(c13, 1), part(c14, 1)}, y17);
+    const View y19 = elan4(M + "19", {{y18, 0}}, 32, 256), y20 = down(M + "20", y19, 256);
+    const View y21 = cbfuse({part(c12, 2), part(c13, 2), part(c14, 2)}, y20);
+    const View y22 = elan4(M + "22", {{y21, 0}}, 64, 512), y23 = down(M + "23", y22, 512);
+    const View y24 = cbfuse({part(c13, 3), part(c14, 3)}, y23);
+    const View y25 = elan4(M + "25", {{y24, 0}}, 128, 1024), y26 = down(M + "26", y25, 1024);
+    const View y27 = cbfuse({part(c14, 4)}, y26);
+    const View y28 = elan4(M + "28", {{y27, 0}}, 128, 1024);
+    const View y29 = sppelan(M + "29", y28, 256, 512);
+    const View y32 = elan4(M + "32", {{y29, 1}, {y25, 0}}, 128, 512);
+    const View y35 = elan4(M + "35", {{y32, 1}, {y22, 0}}, 64, 256);
+    const View y36 = down(M + "36", y35, 256);
+    const View y38 = elan4(M + "38", {{y36, 0}, {y32, 0}}, 128, 512);
+    const View y39 = down(M + "39", y38, 512);
+    const View y41 = elan4(M + "41", {{y39, 0}, {y29, 0}}, 256, 512);
+    P->taps["p3"] = y35.buf; P->taps["p4"] = y38.buf; P->taps["p5"] = y41.buf;
+    const View feats[3] = {y35, y38, y41};
+    head(M + "42.", feats);
+  }
+
   void build() {
+    if (!strcmp(a.size, "e")) { build_e(); return; }
     const std::string M = "model.list.";
     const int cp = Y->cin_pad();
     P->in_buf = new_buf(P->Hn, P->Wn, cp);
@@ -302,31 +402,7 @@ struct Builder {
 
     // DDetect (:157-220)
     const View feats[3] = {y15, y18, y21};
-    Op dec{}; dec.kind = 2;
-    P->A = 0;
-    for (int l = 0; l < 3; ++l) {
-      const std::string hb = M + "22.cv2.list." + std::to_string(l) + ".list.", hc = M + "22.cv3.list." + std::to_string(l) + ".list.";
-      const int H = P->bufs[feats[l].buf].H, W = P->bufs[feats[l].buf].W, ch = a.cls_hidden;
-      const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch), raw = new_buf(H, W, 144, true);
-      conv({{feats[l], 0}}, pconv({hb + "0.conv", hc + "0.conv"}, {1, 1}), whole(hbuf), 1, 1);
-      conv({{slice(whole(hbuf), 0, 64), 0}}, pconv({hb + "1.conv"}, {4}), whole(bxb), 1, 1);
-      conv({{slice(whole(hbuf), 64, ch), 0}}, pconv({hc + "1.conv"}, {1}), whole(clb), 1, 1);
-      conv({{whole(bxb), 0}}, pconv({hb + "2"}, {4}), slice(whole(raw), 0, 64), 1, 0);
-      conv({{whole(clb), 0}}, pconv({hc + "2"}, {1}), slice(whole(raw), 64, 80), 1, 0);
-      P->taps["raw" + std::to_string(l)] = raw;
-      dec.dec.raw[l] = (const float*)(intptr_t)raw; dec.dec.H[l] = H; dec.dec.W[l] = W;
-      P->A += H * W;
-    }
-    dec.dec.B = P->B; dec.dec.A = P->A; dec.dec.dfl_w = Y->dfl_w; dec.dec.conf = 0.25f;
-    P->ops.push_back(dec);
-    Op nms{}; nms.kind = 3;
-    nms.nms.B = P->B; nms.nms.A = P->A; nms.nms.iou_thr = 0.45f;
-    // scale_boxes (:406-416): python-float arithmetic, then f32 tensor ops
-    const double gain = std::min((double)P->Hn / P->H, (double)P->Wn / P->W);
-    nms.nms.gain = (float)gain;
-    nms.nms.pad_x = (float)((P->Wn - P->W * gain) / 2); nms.nms.pad_y = (float)((P->Hn - P->H * gain) / 2);
-    nms.nms.src_w = (float)P->W; nms.nms.src_h = (float)P->H;
-    P->ops.push_back(nms);
+    head(M + "22.", feats);
   }
 
   void resolve() {
@@ -342,6 +418,7 @@ struct Builder {
         op.conv.out = ptr(op.conv.out); op.conv.res = ptr(op.conv.res);
       } else if (op.kind == 1) { op.pool.in = ptr(op.pool.in); op.pool.out = ptr(op.pool.out); }
       else if (op.kind == 2) { for (int l = 0; l < 3; ++l) op.dec.raw[l] = (const float*)ptr(op.dec.raw[l]); op.dec.det = P->det; }
+      else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) op.fuse.in[k] = ptr(op.fuse.in[k]); op.fuse.out = ptr(op.fuse.out); }
       else { op.nms.det = P->det; op.nms.out = P->out_dev; }
     }
   }
@@ -380,6 +457,7 @@ static void run_ops(cc_yolo* Y, Plan* P, hipStream_t s) {
     if (op.kind == 0) launch_conv(Y->dtype, op.conv, s);
     else if (op.kind == 1) launch_pool(Y->dtype, op.pool, s);
     else if (op.kind == 2) launch_decode(op.dec, s);
+    else if (op.kind == 4) launch_fuse(Y->dtype, op.fuse, s);
     else launch_topk_nms(op.nms, s);
   }
 }
@@ -446,7 +524,7 @@ int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device
   CC_CHECK(res > 0 && res % 32 == 0, "res must be a positive multiple of 32");
   const Arch* a = nullptr;
   for (const Arch& x : kArch) if (!strcmp(x.size, size)) a = &x;
-  CC_CHECK(a, std::string("unknown model size '") + size + "' (t, s, m, c)");
+  CC_CHECK(a, std::string("unknown model size '") + size + "' (t, s, m, c, e)");
   int n = 0; CC_HIP(hipGetDeviceCount(&n));
   CC_CHECK(n > 0 && device >= 0 && device < n, "no such HIP device");
   CC_HIP(hipSetDevice(device));
@@ -473,8 +551,9 @@ int cc_yolo_finalize(cc_yolo* h) {
   CC_API_BEGIN
   CC_CHECK(h, "null handle");
   CC_HIP(hipSetDevice(h->device));
-  auto d = h->host.find("model.list.22.dfl.conv.weight");
-  CC_CHECK(d != h->host.end() && d->second.data.size() == 16, "missing parameter model.list.22.dfl.conv.weight");
+  const std::string dfl = std::string("model.list.") + (!strcmp(h->arch->size, "e") ? "42" : "22") + ".dfl.conv.weight";
+  auto d = h->host.find(dfl);
+  CC_CHECK(d != h->host.end() && d->second.data.size() == 16, "missing parameter " + dfl);
   CC_HIP(hipMalloc((void**)&h->dfl_w, 64));
   CC_HIP(hipMemcpy(h->dfl_w, d->second.data.data(), 64, hipMemcpyHostToDevice));
   // dry-run build at B=1, res x res: packs every conv and proves the parameter set is complete
@@ -584,13 +663,14 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
       if (op.kind == 0) launch_conv(h->dtype, op.conv, s);
       else if (op.kind == 1) launch_pool(h->dtype, op.pool, s);
       else if (op.kind == 2) launch_decode(op.dec, s);
+      else if (op.kind == 4) launch_fuse(h->dtype, op.fuse, s);
       else launch_topk_nms(op.nms, s);
       CC_HIP(hipEventRecord(ev[2 * i + 1], s));
     }
     CC_HIP(hipStreamSynchronize(s));
     for (size_t i = 0; i < n; ++i) {
       float t = 0; CC_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
-      acc[P->ops[i].kind] += t;
+      acc[P->ops[i].kind == 4 ? 1 : P->ops[i].kind] += t;
     }
   }
   for (const Op& op : P->ops) if (op.kind == 0) { macs += op.alg_macs; ++nconv; }
@@ -613,7 +693,7 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
           const double bytes = ((double)q.B * q.H * q.W + (double)q.B * q.Ho * q.Wo) * q.C * es;
           fprintf(f, "%zu,pool%d_k%d_s%d,%.4f,%.0f,%d,0,%d,%d,%d,0,0,%.4f,%.0f\n", i, q.mode, q.k, q.stride, t, (double)q.B * q.Ho * q.Wo, q.C, q.k, q.stride, q.C,
                   bytes / 1e9, bytes / (t * 1e-3) / 1e9);
-        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : "topk_nms", t);
+        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : "topk_nms"), t);
       }
       fclose(f);
     }

@@ -88,9 +88,41 @@ def yolo_conv_specs(a: YoloArch) -> List[ConvSpec]:
     return s
 
 
+# YOLOv9-e (detection/yolov9.py:328-371): 43 blocks, auxiliary CBLinear/CBFuse branch, all RepNCSP with n=2.
+YOLO_E_CBLINEAR = {10: (64, [64]), 11: (256, [64, 128]), 12: (512, [64, 128, 256]), 13: (1024, [64, 128, 256, 512]),
+                   14: (1024, [64, 128, 256, 512, 1024])}           # block -> (cin, split sizes); cout = sum(splits)
+YOLO_E_ELAN = {3: (128, 32, 256), 5: (256, 64, 512), 7: (512, 128, 1024), 9: (1024, 128, 1024),
+               19: (128, 32, 256), 22: (256, 64, 512), 25: (512, 128, 1024), 28: (1024, 128, 1024),
+               32: (1536, 128, 512), 35: (1024, 64, 256), 38: (768, 128, 512), 41: (1024, 256, 512)}   # block -> (cin, hid, cout)
+YOLO_E_ADOWN = {4: 256, 6: 512, 8: 1024, 20: 256, 23: 512, 26: 1024, 36: 256, 39: 512}              # block -> channels (in == out)
+
+
+def yolo_e_conv_specs() -> List[ConvSpec]:
+    P = "model.list."
+    s: List[ConvSpec] = [_conv(P + "1", 3, 64, 3), _conv(P + "2", 64, 128, 3), _conv(P + "15", 3, 64, 3), _conv(P + "17", 64, 128, 3)]
+    for i, (cin, hid, cout) in YOLO_E_ELAN.items():
+        s += _elan4(P + str(i), cin, hid, cout, 2)
+    for i, c in YOLO_E_ADOWN.items():
+        s += _down(P + str(i), "adown", c, c)
+    for i, (cin, splits) in YOLO_E_CBLINEAR.items():
+        s.append((P + f"{i}.conv", cin, sum(splits), 1, 1, True))          # bare nn.Conv2d (CBLinear.conv)
+    s += [_conv(P + "29.cv1", 1024, 256, 1), _conv(P + "29.cv5", 1024, 512, 1)]
+    H = P + "42."
+    for lvl, cin in enumerate((256, 512, 512)):
+        s += [_conv(f"{H}cv2.list.{lvl}.list.0", cin, 64, 3), _conv(f"{H}cv2.list.{lvl}.list.1", 64, 64, 3, 4),
+              (f"{H}cv2.list.{lvl}.list.2", 64, 64, 1, 4, True)]
+        s += [_conv(f"{H}cv3.list.{lvl}.list.0", cin, 256, 3), _conv(f"{H}cv3.list.{lvl}.list.1", 256, 256, 3),
+              (f"{H}cv3.list.{lvl}.list.2", 256, 80, 1, 1, True)]
+    return s
+
+
+def yolo_specs(size: str) -> List[ConvSpec]:
+    return yolo_e_conv_specs() if size == "e" else yolo_conv_specs(YOLO_ARCH[size])
+
+
 def yolo_param_count(size: str) -> int:
     n = 16  # dfl
-    for _, cin, cout, k, g, _ in yolo_conv_specs(YOLO_ARCH[size]):
+    for _, cin, cout, k, g, _ in yolo_specs(size):
         n += cout * (cin // g) * k * k + cout
     return n
 
@@ -116,12 +148,12 @@ def synthetic_yolov9_state_dict(size: str = "c", seed: int = 1234, scales=None) 
     144-conv SiLU stack, and class-logit biases of about -5 let a few dozen anchors clear the 0.25
     threshold so top-300 / mask-NMS get real work.  Deterministic: PCG64(seed) + committed table.
     """
-    a = YOLO_ARCH[size]
+    nc = 80
     if scales is None:
         scales = _synth_scales(size)
     rng = np.random.Generator(np.random.PCG64(seed))
     sd: Dict[str, np.ndarray] = {}
-    for prefix, cin, cout, k, g, bare in yolo_conv_specs(a):
+    for prefix, cin, cout, k, g, bare in yolo_specs(size):
         fan_in = (cin // g) * k * k
         w = rng.standard_normal((cout, cin // g, k, k), dtype=np.float32)
         # zero-sum filters: SiLU outputs have a positive mean, and without normalisation layers
@@ -129,11 +161,12 @@ def synthetic_yolov9_state_dict(size: str = "c", seed: int = 1234, scales=None) 
         w -= w.mean(axis=(1, 2, 3), keepdims=True, dtype=np.float64).astype(np.float32)
         w *= np.float32(scales.get(prefix, 1.0) / math.sqrt(fan_in))
         b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
-        if bare and cout == a.nc:
+        if bare and cout == nc and ".cv3." in prefix:
             b = (rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.5) - np.float32(5.0)).astype(np.float32)
         sd[prefix + ".weight"] = w.astype(np.float32)
         sd[prefix + ".bias"] = b.astype(np.float32)
-    sd["model.list.22.dfl.conv.weight"] = np.arange(16, dtype=np.float32).reshape(1, 16, 1, 1)
+    head = 42 if size == "e" else 22
+    sd[f"model.list.{head}.dfl.conv.weight"] = np.arange(16, dtype=np.float32).reshape(1, 16, 1, 1)
     return sd
 
 

@@ -34,7 +34,7 @@ int cc_device_count(int* n);
  * ------------------------------------------------------------------------------------------- */
 typedef struct cc_yolo cc_yolo;
 
-/* YOLOv9.__init__ (yolov9.py:298-326): size in {"t","s","m","c"}, res = letterbox target. */
+/* YOLOv9.__init__ (yolov9.py:298-371): size in {"t","s","m","c","e"}, res = letterbox target. */
 int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device);
 /* load_state_dict (yolov9.py:372-373): one call per state-dict entry, reference key names
  * (SURVEY.md Appendix C), host float32 data, OIHW weights / (Cout,) biases. */

@@ -101,7 +101,11 @@ class YOLOv9Oracle:
     """``YOLOv9(size, res)`` for sizes t/s/m/c with an explicit state dict (no download)."""
 
     def __init__(self, size: str, res: int, state_dict: Dict[str, np.ndarray]):
-        self.arch: YoloArch = YOLO_ARCH[size]
+        self.size = size
+        self.arch = YOLO_ARCH.get(size)              # None for "e" (its graph is spelled out in features_e)
+        self.rep_n = 2 if size == "e" else self.arch.rep_n
+        self.adown_kind = size in ("c", "e")
+        self.head = "model.list.42." if size == "e" else "model.list.22."
         self.res = res
         self.sd = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in state_dict.items()}
 
@@ -126,7 +130,7 @@ class YOLOv9Oracle:
         return self.conv(F.avg_pool2d(x, 2, 1, 0, False, True), p + ".cv1", stride=2)
 
     def down(self, x, p):
-        return self.adown(x, p) if self.arch.down_kind == "adown" else self.aconv(x, p)
+        return self.adown(x, p) if self.adown_kind else self.aconv(x, p)
 
     def elan1(self, x, p):  # :65-80
         y = list(self.conv(x, p + ".cv1").chunk(2, 1))
@@ -136,7 +140,7 @@ class YOLOv9Oracle:
 
     def repncsp(self, x, p):  # :82-105
         x2 = self.conv(x, p + ".cv1")
-        for j in range(self.arch.rep_n):
+        for j in range(self.rep_n):
             q = f"{p}.m.list.{j}"
             x2 = x2 + self.conv(self.conv(x2, q + ".cv1"), q + ".cv2")
         return self.conv(torch.cat((x2, self.conv(x, p + ".cv2")), 1), p + ".cv3")
@@ -158,9 +162,56 @@ class YOLOv9Oracle:
     def upsample(x):  # :285-292
         return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
 
+    # -- YOLOv9-e: auxiliary reversible branch (CBLinear / CBFuse) ---------------------------------
+    def cblinear(self, x, p, splits):  # :222-228 — bare 1x1 conv, then channel split
+        return self._conv2d(x, p + ".conv").split(splits, 1)
+
+    @staticmethod
+    def cbfuse(parts, last):  # :230-245 — nearest-resize the selected splits to the last input's size and sum
+        th, tw = last.shape[2:]
+        acc = None
+        for t in parts:
+            f = th // t.shape[2]
+            u = t.repeat_interleave(f, dim=2).repeat_interleave(tw // t.shape[3], dim=3) if f > 1 else t
+            acc = u if acc is None else acc + u
+        return acc + last                       # Tensor.stack(*res).sum(0): left-to-right sum, xs[-1] last
+
+    def features_e(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """Blocks 0..41 of the "e" graph (:328-370); returns outputs of blocks 35, 38, 41."""
+        from clearcam_amd.weights import YOLO_E_CBLINEAR
+        P = "model.list."
+        y: Dict[int, torch.Tensor] = {0: x}
+        y[1] = self.conv(x, P + "1", stride=2)
+        y[2] = self.conv(y[1], P + "2", stride=2)
+        y[3] = self.elan4(y[2], P + "3"); y[4] = self.adown(y[3], P + "4")
+        y[5] = self.elan4(y[4], P + "5"); y[6] = self.adown(y[5], P + "6")
+        y[7] = self.elan4(y[6], P + "7"); y[8] = self.adown(y[7], P + "8")
+        y[9] = self.elan4(y[8], P + "9")
+        cb = {i: self.cblinear(y[src], P + str(i), YOLO_E_CBLINEAR[i][1]) for i, src in ((10, 1), (11, 3), (12, 5), (13, 7), (14, 9))}
+        y[15] = self.conv(x, P + "15", stride=2)
+        y[16] = self.cbfuse([cb[i][0] for i in (10, 11, 12, 13, 14)], y[15])
+        y[17] = self.conv(y[16], P + "17", stride=2)
+        y[18] = self.cbfuse([cb[i][1] for i in (11, 12, 13, 14)], y[17])
+        y[19] = self.elan4(y[18], P + "19"); y[20] = self.adown(y[19], P + "20")
+        y[21] = self.cbfuse([cb[i][2] for i in (12, 13, 14)], y[20])
+        y[22] = self.elan4(y[21], P + "22"); y[23] = self.adown(y[22], P + "23")
+        y[24] = self.cbfuse([cb[i][3] for i in (13, 14)], y[23])
+        y[25] = self.elan4(y[24], P + "25"); y[26] = self.adown(y[25], P + "26")
+        y[27] = self.cbfuse([cb[14][4]], y[26])
+        y[28] = self.elan4(y[27], P + "28")
+        y[29] = self.sppelan(y[28], P + "29")
+        y[32] = self.elan4(torch.cat((self.upsample(y[29]), y[25]), 1), P + "32")
+        y[35] = self.elan4(torch.cat((self.upsample(y[32]), y[22]), 1), P + "35")
+        y[38] = self.elan4(torch.cat((self.adown(y[35], P + "36"), y[32]), 1), P + "38")
+        y[41] = self.elan4(torch.cat((self.adown(y[38], P + "39"), y[29]), 1), P + "41")
+        self.block_outputs = y
+        return [y[35], y[38], y[41]]
+
     # -- backbone + neck ----------------------------------------------------------------------
     def features(self, x: torch.Tensor) -> List[torch.Tensor]:
         """Blocks 0..21 (:304-325); returns [P3, P4, P5] = outputs of blocks 15, 18, 21."""
+        if self.size == "e":
+            return self.features_e(x)
         P = "model.list."
         y: Dict[int, torch.Tensor] = {}
         y[0] = self.conv(x, P + "0", stride=2)
@@ -183,7 +234,7 @@ class YOLOv9Oracle:
     # -- head ---------------------------------------------------------------------------------
     def head_raw(self, feats: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """``DDetect`` branches (:202-207): per level (B,144,H,W) = cat(box 64, cls 80)."""
-        H = "model.list.22."
+        H = self.head
         out = []
         for i, x in enumerate(feats):
             b = f"{H}cv2.list.{i}.list."
@@ -210,7 +261,7 @@ class YOLOv9Oracle:
         box, cls = cat.split((64, 80), 1)
         a = box.shape[2]
         prob = box.reshape(B, 4, 16, a).transpose(2, 1).softmax(1)
-        dist = F.conv2d(prob, self.sd["model.list.22.dfl.conv.weight"]).reshape(B, 4, a)
+        dist = F.conv2d(prob, self.sd[self.head + "dfl.conv.weight"]).reshape(B, 4, a)
         lt, rb = dist.chunk(2, 1)
         x1y1, x2y2 = anchors - lt, anchors + rb
         dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * strides

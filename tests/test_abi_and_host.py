@@ -50,8 +50,10 @@ def test_missing_weights_message():
     from clearcam_amd.yolov9 import YOLOv9
     with pytest.raises(FileNotFoundError):
         YOLOv9("c", 640, weights="/nonexistent/yolov9-c.safetensors")
+    with pytest.raises(FileNotFoundError):
+        YOLOv9("e", 640, weights="/nonexistent/yolov9-e.safetensors")
     with pytest.raises(ValueError):
-        YOLOv9("e", 640)
+        YOLOv9("x", 640)
 
 
 def test_tensor_shim_and_jit_infer():

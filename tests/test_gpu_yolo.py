@@ -218,6 +218,26 @@ def test_reference_call_surface(sd_t):
     assert boxes.shape == (300, 4) and scores.max() <= 1 and cls.max() < 80
 
 
+def test_yolov9_e_graph_matches_oracle():
+    """The 43-block "e" graph (CBLinear / CBFuse auxiliary branch, yolov9.py:328-371), f32 parity."""
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    sd = synthetic_yolov9_state_dict("e", 1234)
+    frames = noise_frames(1, 1, 640, 640)
+    o = yo.YOLOv9Oracle("e", 640, sd)
+    with torch.no_grad():
+        feats = o.features(o.network_input(frames))
+    ref = o.detect_batch(frames)
+    m = _yolo("e", 640, sd, "f32")
+    got = m.detect_batch(frames)
+    for name, f in zip(("p3", "p4", "p5"), feats):
+        r = f.permute(0, 2, 3, 1).numpy()
+        assert np.sqrt(((m.get_tensor(name) - r) ** 2).mean() / (r ** 2).mean()) < 2e-4, name
+    n_ref, n_got, n_match, box_err, sc_err = yo.match_detections(ref[0], got[0], 0.9)
+    assert n_ref > 50 and n_match >= 0.99 * max(n_ref, n_got) - 1 and box_err <= 0.64 and sc_err <= 1e-3, (n_ref, n_got, n_match, box_err)
+    bf = _yolo("e", 640, sd, "bf16").detect_batch(frames)
+    assert np.isfinite(bf).all() and (bf[..., 4] > 0).sum() > 0
+
+
 def test_small_model_sizes_run(sd_t):
     from clearcam_amd.weights import synthetic_yolov9_state_dict
     for size in ("s", "m"):

@@ -22,6 +22,7 @@ def test_param_counts_match_published():
     assert yolo_param_count("s") == 7_105_888
     assert yolo_param_count("m") == 19_978_672
     assert yolo_param_count("c") == 25_288_768
+    assert abs(yolo_param_count("e") / 1e6 - 57.3) < 0.1       # YOLOv9-E: 57.3 M (paper)
 
 
 def test_state_dict_keys_follow_reference_attribute_tree(sd_c):

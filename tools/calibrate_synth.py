@@ -31,8 +31,8 @@ def calibrate(size: str, seed: int = 1234, res: int = 640):
             target = 1.0
             if ".m.list." in name and name.endswith("cv2.conv"):
                 target = 0.6                      # residual branch
-            is_cls = "model.list.22.cv3.list" in name and name.endswith(".list.2")
-            if "cv2.list" in name and name.endswith(".list.2") and "model.list.22" in name:
+            is_cls = (".cv3.list" in name) and name.endswith(".list.2") and ("model.list.22." in name or "model.list.42." in name)
+            if "cv2.list" in name and name.endswith(".list.2") and ("model.list.22." in name or "model.list.42." in name):
                 target = 2.0                      # DFL logits
             b = o.sd[name + ".bias"]
             z = y - b.view(1, -1, 1, 1)
@@ -54,7 +54,7 @@ def calibrate(size: str, seed: int = 1234, res: int = 640):
 
 
 if __name__ == "__main__":
-    out = {s: calibrate(s) for s in "tsmc"}
+    out = {s: calibrate(s) for s in "tsmce"}
     path = os.path.join(os.path.dirname(W.__file__), "assets", "synth_scales.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
