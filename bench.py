@@ -123,6 +123,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", default="c")
     ap.add_argument("--res", type=int, default=640)
+    ap.add_argument("--height", type=int, default=0, help="source frame height (default: res)")
+    ap.add_argument("--width", type=int, default=0, help="source frame width (default: res)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clip", action="store_true", help="skip the CLIP / search side metrics")
@@ -147,7 +149,8 @@ def main() -> None:
     sd = synthetic_yolov9_state_dict(args.size, 1234)
     model = YOLOv9(args.size, args.res, state_dict=sd, dtype=args.dtype, device=local)
     B = args.batch
-    frames = torch.from_numpy(np.random.default_rng(1 + rank).integers(0, 256, (B, args.res, args.res, 3), dtype=np.uint8)).to(dev)
+    fh, fw = args.height or args.res, args.width or args.res
+    frames = torch.from_numpy(np.random.default_rng(1 + rank).integers(0, 256, (B, fh, fw, 3), dtype=np.uint8)).to(dev)
     out = torch.empty((B, 300, 6), dtype=torch.float32, device=dev)
 
     def barrier():
@@ -180,11 +183,12 @@ def main() -> None:
         achieved = alg_flops / conv_s / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         line = {
-            "metric": f"yolov9{args.size}_{args.res}x{args.res}_frames_per_sec",
+            "metric": f"yolov9{args.size}_{args.res}x{args.res}_frames_per_sec" if (fh, fw) == (args.res, args.res)
+                      else f"yolov9{args.size}_{fh}x{fw}_letterbox{args.res}_frames_per_sec",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"YOLOv9-{args.size.upper()} {args.dtype} batch={B} {args.res}x{args.res} per GPU, "
+            "config": {"workload": f"YOLOv9-{args.size.upper()} {args.dtype} batch={B} {fh}x{fw} frames (letterbox {args.res}) per GPU, "
                                    f"uint8 BGR frames resident in HBM, seeded synthetic weights, full detect path "
                                    f"(letterbox+convs+decode+top300+NMS)",
                        "batch_per_gpu": B, "parallelism": f"one camera batch per GPU x{world}, no collective",

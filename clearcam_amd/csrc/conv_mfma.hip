@@ -370,8 +370,15 @@ static void launch_k(const ConvP& p, const ConvAux& a, int mtiles, hipStream_t s
   hipLaunchKernelGGL((conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>), dim3(mtiles * a.nt), dim3(2 * BM), lds, stream, p, a);
 }
 
+static int g_thin_k = -1;     // K (elements) at or below which the 64-byte-row / 5-blocks-per-CU variant is used
+
 template <class T, int BN, bool SIMPLE>
 static void launch_cfg(const ConvP& p, const ConvAux& a, int M, int bm, int ns, hipStream_t stream) {
+  if (g_thin_k < 0) { const char* e = getenv("CLEARCAM_THIN_K"); g_thin_k = e ? atoi(e) : 256; }
+  if (p.Ktot * (int)sizeof(T) <= g_thin_k * 2) {        // few K steps: latency-bound -> favour occupancy over step size
+    launch_k<T, 128, BN, 2, SIMPLE, 4, 2>(p, a, (M + 127) / 128, stream);
+    return;
+  }
   if (bm == 256) {
     const int mt = (M + 255) / 256;
     if (ns == 3) launch_k<T, 256, BN, 4, SIMPLE, 8, 3>(p, a, mt, stream); else launch_k<T, 256, BN, 4, SIMPLE, 8, 2>(p, a, mt, stream);
