@@ -34,6 +34,9 @@
 namespace cc {
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+#ifndef CC_ABL
+#define CC_ABL 0   // compile-time ablation bits for timing experiments only (wrong results): 1 no DMA, 2 no ds_read, 4 no MFMA
+#endif
 
 struct ConvAux {
   float inv_hw, inv_wo;   // 1/(Ho*Wo), 1/Wo for divide-free pixel decomposition
@@ -103,6 +106,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // SIMPLE: one source, no upsample, ks <= 3 -> incremental row pointers.  !SIMPLE: general two-source / upsample path.
 // NS = LDS stages: the DMA of step t+NS-1 is issued while step t computes (prefetch distance NS-1 steps).
 // BM = pixels per tile (128 -> 4 waves, 256 -> 8 waves: half the L2->LDS weight traffic per flop).
+// (A ping-pong schedule and a register-staged loader were measured and dropped: DESIGN.md §4.)
 template <class T, int BM, int BN, int WM, bool SIMPLE, int CPRW, int NS>
 __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const ConvAux a) {
   constexpr int NT = 2 * BM, WN = NT / 64 / WM;
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  {
   // prologue: steps 0 .. NS-2 in flight
   int issued = 0;
 #pragma unroll
@@ -253,22 +258,37 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
     else if (NS > 2 && ahead >= 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __syncthreads();                                   // ... for every wave; the stage consumed at step kt-1 is free again
-    if (issued < nkt) { advance_k(); issue_loads(st_i); ++issued; if (++st_i == NS) st_i = 0; }
+    if (issued < nkt) { advance_k(); if (!(CC_ABL & 1)) issue_loads(st_i); ++issued; if (++st_i == NS) st_i = 0; }
     const uint4* ldsX = lds + st_c * STAGE;
     const uint4* ldsW = ldsX + BM * CPRW;
     if (++st_c == NS) st_c = 0;
 #pragma unroll
     for (int h = 0; h < CPRW / 4; ++h) {
       uint4 xf[MI], wf[NJ];
+      if constexpr (!(CC_ABL & 2)) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) { const int row = wm0 + i * 16 + fr; xf[i] = ldsX[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
+        for (int i = 0; i < MI; ++i) { const int row = wm0 + i * 16 + fr; xf[i] = ldsX[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) { const int row = wn0 + j * 16 + fr; wf[j] = ldsW[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
+        for (int j = 0; j < NJ; ++j) { const int row = wn0 + j * 16 + fr; wf[j] = ldsW[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
+      } else {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+        for (int i = 0; i < MI; ++i) { xf[i] = make_uint4(kt + i, lane, h, 1); asm volatile("" : "+v"(xf[i].x), "+v"(xf[i].y), "+v"(xf[i].z), "+v"(xf[i].w)); }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+        for (int j = 0; j < NJ; ++j) { wf[j] = make_uint4(kt + j, lane, h, 2); asm volatile("" : "+v"(wf[j].x), "+v"(wf[j].y), "+v"(wf[j].z), "+v"(wf[j].w)); }
+      }
+      if constexpr (!(CC_ABL & 4)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int i = 0; i < MI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int i = 0; i < MI; ++i) { acc[j][i][0] += __uint_as_float(wf[j].x ^ xf[i].x); }
+      }
     }
+  }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
@@ -381,10 +401,12 @@ static void launch_cfg(const ConvP& p, const ConvAux& a, int M, int bm, int ns, 
   }
   if (bm == 256) {
     const int mt = (M + 255) / 256;
-    if (ns == 3) launch_k<T, 256, BN, 4, SIMPLE, 8, 3>(p, a, mt, stream); else launch_k<T, 256, BN, 4, SIMPLE, 8, 2>(p, a, mt, stream);
+    if (ns == 3) launch_k<T, 256, BN, 4, SIMPLE, 8, 3>(p, a, mt, stream);
+    else launch_k<T, 256, BN, 4, SIMPLE, 8, 2>(p, a, mt, stream);
   } else {
     const int mt = (M + 127) / 128;
-    if (ns == 3) launch_k<T, 128, BN, 2, SIMPLE, 8, 3>(p, a, mt, stream); else launch_k<T, 128, BN, 2, SIMPLE, 8, 2>(p, a, mt, stream);
+    if (ns == 3) launch_k<T, 128, BN, 2, SIMPLE, 8, 3>(p, a, mt, stream);
+    else launch_k<T, 128, BN, 2, SIMPLE, 8, 2>(p, a, mt, stream);
   }
 }
 
@@ -393,7 +415,8 @@ template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const Conv
     g_cfg[0] = 128; g_cfg[1] = 2; g_cfg[2] = 128; g_cfg[3] = 2;
     if (const char* e = getenv("CLEARCAM_CONV_CFG")) sscanf(e, "%d,%d,%d,%d", &g_cfg[0], &g_cfg[1], &g_cfg[2], &g_cfg[3]);
   }
-  if (bn == 128) launch_cfg<T, 128, SIMPLE>(p, a, M, g_cfg[0], g_cfg[1], stream);
+  if (bn == 256) launch_k<T, 256, 256, 4, SIMPLE, 8, 2>(p, a, (M + 255) / 256, stream);
+  else if (bn == 128) launch_cfg<T, 128, SIMPLE>(p, a, M, g_cfg[0], g_cfg[1], stream);
   else if (bn == 64) launch_cfg<T, 64, SIMPLE>(p, a, M, g_cfg[2], g_cfg[3], stream);
   else launch_k<T, 128, 32, 4, SIMPLE, 8, 2>(p, a, (M + 127) / 128, stream);
 }
@@ -404,9 +427,16 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   int bn = 128;
   if (padded(64) < padded(bn)) bn = 64;
   if (padded(32) < padded(bn)) bn = 32;
+  {   // 256x256 tiles (3.9 B of L1 traffic per kFLOP instead of 7.8) for wide, deep GEMMs: opt-in with CLEARCAM_BIG_TILE=1
+      // (measured equal to 128x128 within 3 %: the single 8-wave block per CU loses what the halved L1 traffic gains)
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("CLEARCAM_BIG_TILE"); big = e ? atoi(e) : 0; }
+    if (big && sizeof(T) == 2 && p.Cout % 256 == 0 && p.Ktot >= big * 512 && M >= 256 * 256) bn = 256;
+  }
   ConvAux a{};
   a.nt = (p.Cout + bn - 1) / bn;
   a.inv_hw = 1.0f / (float)(p.Ho * p.Wo); a.inv_wo = 1.0f / (float)p.Wo;
+
   const bool simple = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
   a.is1x1 = simple && p.ks == 1 && p.stride == 1 && p.pad == 0 && p.Hin == p.Ho && p.Win == p.Wo;
   if (simple) launch_ts<T, true>(p, a, bn, M, stream); else launch_ts<T, false>(p, a, bn, M, stream);
