@@ -13,7 +13,7 @@ SYMBOLS = [
     "cc_yolo_create", "cc_yolo_load", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_get_tensor",
     "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_destroy", "cc_conv2d_nhwc",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
-    "cc_clip_last_gpu_ms", "cc_clip_destroy",
+    "cc_clip_last_gpu_ms", "cc_clip_destroy", "cc_crop_preprocess",
     "cc_index_create", "cc_index_add", "cc_index_size", "cc_index_scores", "cc_index_search", "cc_index_destroy",
 ]
 
@@ -59,6 +59,7 @@ def lib() -> C.CDLL:
         "cc_clip_encode_image": [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_clip_encode_text": [vp, vp, C.c_int, vp, C.c_int, vp],
         "cc_clip_last_gpu_ms": [vp, fp],
+        "cc_crop_preprocess": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_index_create": [C.POINTER(vp), C.c_int, C.c_int64, C.c_int],
         "cc_index_add": [vp, vp, C.c_int64, C.c_int],
         "cc_index_size": [vp, i64p],

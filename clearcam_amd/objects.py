@@ -158,6 +158,27 @@ class EmbeddingIndex:
             pass
 
 
+def preprocess_crops(crops, size: int = 224, device: int = 0):
+    """cc_crop_preprocess over a list of (H,W,3) uint8 arrays (host) -> torch device tensor (B,3,size,size) f32."""
+    import torch
+    crops = [np.ascontiguousarray(c, dtype=np.uint8) for c in crops]
+    for c in crops:
+        if c.ndim != 3 or c.shape[2] != 3 or c.size == 0:
+            raise ValueError(f"crop must be a non-empty (H,W,3) uint8 array, got {c.shape}")
+    B = len(crops)
+    if B == 0:
+        raise ValueError("no crops")
+    sizes = np.array([c.size for c in crops], np.int64)
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    packed = np.concatenate([c.reshape(-1) for c in crops])
+    hs = np.array([c.shape[0] for c in crops], np.int32)
+    ws = np.array([c.shape[1] for c in crops], np.int32)
+    out = torch.empty((B, 3, size, size), dtype=torch.float32, device=torch.device("cuda", device))
+    _lib.check(_lib.lib().cc_crop_preprocess(_lib.ptr(packed), _lib.ptr(offsets), _lib.ptr(hs), _lib.ptr(ws), B, 0, size, _lib.ptr(out), device,
+                                   torch.cuda.current_stream(device).cuda_stream))
+    return out
+
+
 class ObjectFinder:
     """``models/objects.py:188-422`` minus the face pipeline (out of scope)."""
 
@@ -189,11 +210,14 @@ class ObjectFinder:
         self.model = None
 
     def preprocess(self, img):
-        """:237-242 — needs OpenCV's INTER_CUBIC resize, exactly as the reference does (host side)."""
-        import cv2
-        img = cv2.resize(img, (224, 224), interpolation=cv2.INTER_CUBIC)
-        img = (img.astype(np.float32) / 255.0 - 0.5) / 0.5
-        return np.transpose(img, (2, 0, 1))
+        """:237-242 — cv2.resize(img,(224,224),INTER_CUBIC) -> f32/255 -> (x-0.5)/0.5 -> CHW, on the GPU
+        (cc_crop_preprocess: OpenCV's 8-bit fixed-point cubic).  Returns (3,224,224) float32 like the reference."""
+        return self.preprocess_crops([img]).cpu().numpy()[0]
+
+    def preprocess_crops(self, crops, size: int = 224, device: Optional[int] = None):
+        """Batch form of :237-242: list of (H,W,3) uint8 crops of any size -> device tensor (B,3,size,size) float32,
+        the input `OpenCLIP.precompute_embedding_device` takes.  One H2D copy of the packed crops, one kernel."""
+        return preprocess_crops(crops, size, self.model.device if (device is None and self.model) else (device or 0))
 
     # -- store ------------------------------------------------------------------------------------
     def _load_all_embeddings(self, face: bool = False):

@@ -89,6 +89,14 @@ int cc_clip_encode_text(cc_clip* h, const int32_t* tokens, int B, float* out, in
 int cc_clip_last_gpu_ms(cc_clip* h, float* ms);
 void cc_clip_destroy(cc_clip* h);
 
+/* `ObjectFinder.preprocess(img)` (models/objects.py:237-242) for a batch of crops: cv2.resize(img,(S,S),INTER_CUBIC)
+ * (OpenCV 4.10 8-bit fixed-point cubic, requirements.txt:3) -> float32/255 -> (x-0.5)/0.5 -> HWC->CHW.
+ * pixels: packed uint8 HWC crops (3 channels, channel order untouched), crop b = heights[b] x widths[b] starting at
+ * byte offsets[b]; the three tables are host arrays.  out_dev: device float32 (B,3,S,S), ready for
+ * cc_clip_encode_image(x_on_device=1).  Synchronises `stream` before returning. */
+int cc_crop_preprocess(const uint8_t* pixels, const int64_t* offsets, const int32_t* heights, const int32_t* widths,
+                       int B, int pixels_on_device, int out_size, float* out_dev, int device, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Embedding index — stands behind the scoring loop of `ObjectFinder.search`
  * (models/objects.py:365-376: sim = img_emb @ text_emb.T per item) over a device-resident matrix.

@@ -128,3 +128,41 @@ def test_object_finder_search_matches_reference_loop(tiny):
         assert [p for p, _ in got] == [p for p, _ in ref]
         assert np.allclose([s for _, s in got], [s for _, s in ref], atol=1e-6)
     assert ObjectFinder().search(text_embedding=q) == []
+
+
+def _crops(rng):
+    shapes = [(1, 1), (2, 3), (3, 5), (57, 131), (224, 224), (225, 223), (500, 300), (97, 1200), (1080, 64)]
+    return [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+
+
+def test_crop_preprocess_bit_exact_vs_opencv_restatement():
+    """cc_crop_preprocess == oracle/cv_resize_oracle (OpenCV 4.10 8-bit INTER_CUBIC restatement), bit for bit,
+    on ragged crop sizes incl. 1x1, up- and down-scaling and non-square aspect (models/objects.py:237-242)."""
+    from clearcam_amd.objects import ObjectFinder, preprocess_crops
+    from oracle.cv_resize_oracle import preprocess
+    crops = _crops(np.random.default_rng(7))
+    got = preprocess_crops(crops).cpu().numpy()
+    assert got.shape == (len(crops), 3, 224, 224) and got.dtype == np.float32
+    for c, g in zip(crops, got):
+        assert np.array_equal(preprocess(c), g)
+    one = ObjectFinder().preprocess(crops[3])                            # the reference's single-image surface
+    assert one.shape == (3, 224, 224) and np.array_equal(one, got[3])
+    smooth = np.clip(np.add.outer(np.arange(300), np.arange(200))[:, :, None] * np.array([0.5, 0.3, 0.7]), 0, 255).astype(np.uint8)
+    assert np.array_equal(preprocess_crops([smooth], 56).cpu().numpy()[0], preprocess(smooth, 56))
+    with pytest.raises(ValueError):
+        preprocess_crops([np.zeros((0, 4, 3), np.uint8)])
+
+
+def test_crops_to_embeddings_chain(tiny):
+    """crop -> cubic preprocess -> precompute_embedding entirely on the device == oracle chain (clearcam.py:1280-1285)."""
+    import torch
+    from clearcam_amd.objects import OpenCLIP, preprocess_crops
+    from oracle.cv_resize_oracle import preprocess
+    sd, o = tiny
+    crops = _crops(np.random.default_rng(8))
+    m = OpenCLIP(state_dict=sd, arch=CLIP_TINY, dtype="f32")
+    x = preprocess_crops(crops, CLIP_TINY.image_size)
+    emb = torch.empty(len(crops), CLIP_TINY.embed, device=x.device)
+    m.precompute_embedding_device(x, emb)
+    ref = o.precompute_embedding(np.stack([preprocess(c, CLIP_TINY.image_size) for c in crops]))
+    assert np.abs(emb.cpu().numpy() - ref).max() < 1e-5

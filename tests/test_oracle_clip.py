@@ -100,3 +100,23 @@ def test_search_reference_semantics():
     assert len(search_reference(d, q, cam_name="back")) == 2
     assert len(search_reference(d, q, timestamp="2026-01-02")) == 1
     assert len(search_reference(d, q, top_k=1)) == 1
+
+
+def test_cubic_resize_oracle_properties():
+    """oracle/cv_resize_oracle.py: identity at equal size, constants preserved, and agreement (<= 1 LSB, fixed point vs
+    float) with an independent float implementation of the same kernel (A=-0.75, replicate border): torch bicubic."""
+    import torch
+    from oracle.cv_resize_oracle import preprocess, resize_cubic_u8
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    assert np.array_equal(resize_cubic_u8(a), a)
+    assert np.unique(resize_cubic_u8(np.full((40, 30, 3), 200, np.uint8))).tolist() == [200]
+    for h, w in [(57, 131), (3, 5), (400, 90)]:
+        b = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        r = resize_cubic_u8(b)
+        t = torch.from_numpy(b.astype(np.float32)).permute(2, 0, 1)[None]
+        f = torch.nn.functional.interpolate(t, size=(224, 224), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(np.clip(np.rint(f), 0, 255) - r.astype(np.float32)).max() <= 1
+    p = preprocess(a)
+    assert p.shape == (3, 224, 224) and p.dtype == np.float32 and p.min() >= -1 and p.max() <= 1
+    assert p[0, 0, 0] == np.float32((np.float32(a[0, 0, 0]) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5))
