@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
 def _newer(dst, srcs):
@@ -28,7 +28,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers.append(os.path.join(os.path.dirname(HERE), "include", "clearcam_hip.h"))
     jobs = []
     for src in sources():
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
         if force or not _newer(obj, [src] + headers):
             jobs.append((src, obj))
 
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(compile_one, jobs))
-    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in sources()]
+    objs = [os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o") for s in sources()]
     if force or jobs or not _newer(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)

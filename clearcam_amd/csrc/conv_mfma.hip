@@ -295,6 +295,7 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
   if constexpr (sizeof(T) == 2) {
     constexpr int ROWB = BN * 2;                       // epilogue tile row (bytes), chunk-swizzled, no padding
     constexpr int CPR = BN / 8;                        // 16-byte chunks per row
+    auto rowswz = [](int row) { if constexpr (CPR <= 16) return row / (16 / CPR); else return row * (CPR / 16); };
     if (!p.res && !p.out_f32 && (p.Cout % 8 == 0) && (p.out_coff % 8 == 0) && (p.out_cstride % 8 == 0)) {
       __syncthreads();                                 // every wave is done reading the K stages
       char* tilep = reinterpret_cast<char*>(lds);
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
             const float v0 = activate<T, ACT>(acc[j][i][0] + b4.x), v1 = activate<T, ACT>(acc[j][i][1] + b4.y);
             const float v2 = activate<T, ACT>(acc[j][i][2] + b4.z), v3 = activate<T, ACT>(acc[j][i][3] + b4.w);
             const int row = wm0 + i * 16 + fr;
-            const int ch = (nl >> 3) ^ ((row / (16 / CPR)) & (CPR - 1));
+            const int ch = (nl >> 3) ^ (rowswz(row) & (CPR - 1));
             *reinterpret_cast<uint2*>(tilep + row * ROWB + ch * 16 + (nl & 4) * 2) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
           }
         }
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
         const int m = m0 + row;
         if (m < M && n0 + ch * 8 < p.Cout)
           *reinterpret_cast<uint4*>(outp + (size_t)m * p.out_cstride + ch * 8) =
-              *reinterpret_cast<const uint4*>(tilep + row * ROWB + (ch ^ ((row / (16 / CPR)) & (CPR - 1))) * 16);
+              *reinterpret_cast<const uint4*>(tilep + row * ROWB + (ch ^ (rowswz(row) & (CPR - 1))) * 16);
       }
       return;
     }

@@ -98,6 +98,19 @@ int cc_crop_preprocess(const uint8_t* pixels, const int64_t* offsets, const int3
                        int B, int pixels_on_device, int out_size, float* out_dev, int device, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * OC-SORT tracker (host code, no GPU) — stands behind `OCSort(...)` / `OCSort.update(preds, thresh)`
+ * (ocsort_tracker/ocsort.py:164-308), the consumer of the detector output (clearcam.py:239,585).
+ * dets: n rows [x1,y1,x2,y2,score,class] float32 exactly as cc_yolo_detect writes them (zero rows allowed).
+ * out: up to cap rows of 9 doubles [tlx,tly,w,h,track_id,tracklet_len,class_id,score,speed] = the STrack fields
+ * (ocsort_tracker/STrack.py:5-17), newest track first; *n_out = rows produced.  One handle per camera.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cc_ocsort cc_ocsort;
+int cc_ocsort_create(cc_ocsort** h, int max_age, int min_hits, double iou_threshold, int delta_t, double inertia, int use_byte);
+int cc_ocsort_update(cc_ocsort* h, const float* dets, int n, double det_thresh, double* out, int cap, int* n_out);
+int cc_ocsort_num_tracks(cc_ocsort* h, int* n);
+void cc_ocsort_destroy(cc_ocsort* h);
+
+/* ---------------------------------------------------------------------------------------------
  * Embedding index — stands behind the scoring loop of `ObjectFinder.search`
  * (models/objects.py:365-376: sim = img_emb @ text_emb.T per item) over a device-resident matrix.
  * Path filtering / best-per-track-id / sorting of the reference stay in the Python shim.

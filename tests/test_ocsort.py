@@ -1,0 +1,82 @@
+"""C++ OC-SORT (csrc/ocsort.cpp behind clearcam_amd.ocsort.OCSort) against golden sequences produced by the reference
+tracker itself (tools/make_ocsort_golden.py runs /root/reference/ocsort_tracker on seeded scenes).  Host-only: no GPU.
+The comparison is the reference's own (test/test_ocsort.py:9-17): same tracks per frame, rtol 1e-5 — plus exact ids."""
+import os
+
+import numpy as np
+import pytest
+
+from clearcam_amd.ocsort import OCSort, STrack
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLD, f"ocsort_{name}.npz"))
+    kw = {k[3:]: float(g[k]) for k in g.files if k.startswith("kw_")}
+    for k in ("max_age", "min_hits", "delta_t"):
+        if k in kw:
+            kw[k] = int(kw[k])
+    if "use_byte" in kw:
+        kw["use_byte"] = bool(kw["use_byte"])
+    frames, di = [], 0
+    for n in g["dets_per_frame"]:
+        d = np.zeros((300, 6), np.float32)                      # detector-shaped: zero rows are suppressed detections
+        d[:n] = g["dets"][di:di + n]
+        di += n
+        frames.append(d)
+    exp, oi = [], 0
+    for n in g["out_per_frame"]:
+        exp.append(g["out"][oi:oi + n])
+        oi += n
+    return kw, float(g["thresh"]), frames, exp, int(g["alive"])
+
+
+@pytest.mark.parametrize("name", ["street", "mot", "byte", "sparse"])
+def test_matches_reference_tracker(name):
+    kw, thresh, frames, exp, alive = _load(name)
+    trk = OCSort(**kw)
+    total = 0
+    for f, (det, e) in enumerate(zip(frames, exp)):
+        out = trk.update(det, thresh)
+        assert len(out) == len(e), f"frame {f}: {len(out)} tracks, reference {len(e)}"
+        for t, r in zip(out, e):
+            assert t.track_id == r[4] and t.tracklet_len == r[5] and t.class_id == r[6], f"frame {f}"
+            np.testing.assert_allclose(np.concatenate([t.tlwh, [t.score, t.speed]]), np.concatenate([r[:4], r[7:9]]), rtol=1e-5, atol=1e-9)
+        total += len(e)
+    assert total > 0 and trk.num_tracks() == alive and trk.frame_count == len(frames)
+
+
+def test_call_surface():
+    trk = OCSort(max_age=100)                                    # clearcam.py:239
+    assert isinstance(trk.update(None), np.ndarray) and trk.update(None).shape == (0, 5)       # ocsort.py:194-195
+    assert trk.update(np.zeros((300, 6), np.float32), 0.25) == []                                # a frame without detections
+    det = np.zeros((300, 6), np.float32)
+    det[0] = [100, 120, 180, 300, 0.9, 2]
+    det[1] = [400, 50, 460, 200, 0.2, 0]                         # below thresh: ignored without BYTE
+    out = trk.update(det, 0.25)
+    assert len(out) == 1 and isinstance(out[0], STrack)
+    t = out[0]
+    # a fresh track reports its Kalman state (x,y,s,r round trip of the float32 box), id 1, the creating score
+    np.testing.assert_allclose(t.tlwh, [100, 120, 80, 180], rtol=1e-5)
+    np.testing.assert_allclose(t.tlbr, [100, 120, 180, 300], rtol=1e-5)
+    assert t.track_id == 1 and t.class_id == 2 and t.tracklet_len == 0 and t.speed == 0 and abs(t.score - 0.9) < 1e-6
+    for k in range(1, 4):                                        # steady motion: same id, speed grows, box = last observation
+        det[0, :4] += [5, 0, 5, 0]
+        out = trk.update(det, 0.25)
+    assert [x.track_id for x in out] == [1] and out[0].tracklet_len == 3 and out[0].speed > 0
+    np.testing.assert_array_equal(out[0].tlbr.astype(np.float32), det[0, :4])
+    with pytest.raises(ValueError):
+        trk.update(np.zeros((4, 5), np.float32))
+    with pytest.raises(ValueError):
+        OCSort(asso_func="giou")
+    trk.close()
+
+
+def test_many_cameras_are_independent():
+    kw, thresh, frames, exp, _ = _load("street")
+    a, b = OCSort(**kw), OCSort(**kw)
+    for f in range(40):
+        ra = a.update_rows(frames[f], thresh)
+        rb = b.update_rows(frames[f], thresh)                    # ids are per tracker (the reference shares one global counter)
+        np.testing.assert_array_equal(ra, rb)

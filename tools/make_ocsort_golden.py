@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ocsort_*.npz by running the REFERENCE tracker (/root/reference/ocsort_tracker, pure numpy,
+numpy 2.x semantics as requirements.txt pins) on seeded synthetic detection sequences.  Runs only in the build
+container (the reference is not present on the GPU box); the fixtures are what travels.
+
+Each fixture holds, per frame, the detector-shaped input (300,6) float32 [x1,y1,x2,y2,score,cls] with zero rows for
+padding (what YOLOv9.__call__ returns, detection/yolov9.py:439-458) and the tracker's output rows
+[tlx,tly,w,h,track_id,tracklet_len,class_id,score,speed] (STrack fields, ocsort_tracker/ocsort.py:299-308).
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, "/root/reference")
+from ocsort_tracker import ocsort  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def scene(seed, n_frames, n_obj, W=1920, H=1080, miss=0.08, occlude=True, low_score=0.15, crowd=False):
+    """Moving boxes with births/deaths, random misses, long occlusions (exercises the ORU re-update), jitter,
+    low-score detections (BYTE band), false positives, class flicker and crossing paths."""
+    rng = np.random.default_rng(seed)
+    objs = []
+    for i in range(n_obj):
+        w, h = rng.uniform(40, 220), rng.uniform(60, 320)
+        if crowd:
+            cx, cy = rng.uniform(600, 1300), rng.uniform(300, 800)
+        else:
+            cx, cy = rng.uniform(0, W), rng.uniform(0, H)
+        v = rng.normal(0, 6 if not crowd else 3, 2)
+        if i % 5 == 0:
+            v *= 0.02                                            # near-static objects (speed filter)
+        born = int(rng.integers(0, n_frames // 2)) if i % 3 else 0
+        dies = int(rng.integers(born + 5, n_frames + 40))
+        occ0 = int(rng.integers(born + 3, max(born + 4, dies))) if occlude and i % 2 == 0 else 10 ** 9
+        occ_len = int(rng.integers(2, 45))
+        objs.append(dict(c=np.array([cx, cy]), wh=np.array([w, h]), v=v, born=born, dies=dies, occ=(occ0, occ0 + occ_len),
+                         cls=int(rng.integers(0, 4)), acc=rng.normal(0, 0.15, 2)))
+    frames = []
+    for t in range(n_frames):
+        rows = []
+        for o in objs:
+            o["v"] = o["v"] + o["acc"] * rng.normal(0, 1, 2)
+            o["c"] = o["c"] + o["v"]
+            o["wh"] = np.maximum(o["wh"] * (1 + rng.normal(0, 0.01, 2)), 8)
+            if not (o["born"] <= t < o["dies"]) or (o["occ"][0] <= t < o["occ"][1]) or rng.random() < miss:
+                continue
+            j = rng.normal(0, 1.5, 4)
+            x1, y1 = o["c"] - o["wh"] / 2
+            x2, y2 = o["c"] + o["wh"] / 2
+            box = np.array([x1, y1, x2, y2]) + j
+            box[[0, 2]] = np.clip(box[[0, 2]], 0, W)
+            box[[1, 3]] = np.clip(box[[1, 3]], 0, H)
+            if box[2] - box[0] < 2 or box[3] - box[1] < 2:
+                continue
+            score = float(np.clip(rng.normal(0.7, 0.15), 0.05, 0.99))
+            if rng.random() < low_score:
+                score = float(rng.uniform(0.11, 0.24))
+            cls = o["cls"] if rng.random() > 0.1 else int(rng.integers(0, 4))
+            rows.append([*box, score, cls])
+        for _ in range(int(rng.poisson(0.3))):                   # false positives
+            x, y = rng.uniform(0, W - 60), rng.uniform(0, H - 60)
+            rows.append([x, y, x + rng.uniform(10, 60), y + rng.uniform(10, 60), float(rng.uniform(0.26, 0.5)), int(rng.integers(0, 80))])
+        rows.sort(key=lambda r: -r[4])                           # the detector emits rows in descending score order
+        det = np.zeros((300, 6), np.float32)
+        if rows:
+            det[:len(rows)] = np.array(rows, np.float32)[:300]
+        frames.append(det)
+    return np.stack(frames)
+
+
+def run(frames, thresh, **kw):
+    trk = ocsort.OCSort(**kw)
+    outs, counts = [], []
+    for det in frames:
+        res = trk.update(det, thresh)
+        rows = [[x.tlwh[0], x.tlwh[1], x.tlwh[2], x.tlwh[3], x.track_id, x.tracklet_len, x.class_id, x.score, x.speed] for x in res]
+        outs.extend(rows)
+        counts.append(len(rows))
+    return np.array(outs, np.float64).reshape(-1, 9), np.array(counts, np.int32), len(trk.trackers)
+
+
+CASES = {
+    # name: (scene kwargs, thresh, tracker kwargs)
+    "street": (dict(seed=11, n_frames=240, n_obj=14), 0.25, dict(max_age=100)),                # clearcam.py:239
+    "mot": (dict(seed=12, n_frames=200, n_obj=40, crowd=True, miss=0.12), 0.25, dict(max_age=60)),   # test/run_mot.py:14
+    "byte": (dict(seed=13, n_frames=160, n_obj=16, low_score=0.35), 0.4, dict(max_age=30, use_byte=True, min_hits=2, delta_t=2)),
+    "sparse": (dict(seed=14, n_frames=120, n_obj=3, miss=0.4), 0.25, dict(max_age=5, iou_threshold=0.2, inertia=0.4)),
+}
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for name, (skw, thresh, tkw) in CASES.items():
+        frames = scene(**skw)
+        rows, counts, alive = run(frames, thresh, **tkw)
+        nz = int((frames[..., 4] > 0).sum())
+        # store only the non-zero detection rows to keep the fixture small
+        n_per = (frames[..., 4] > 0).sum(1).astype(np.int32)
+        packed = np.concatenate([f[:n] for f, n in zip(frames, n_per)]) if nz else np.zeros((0, 6), np.float32)
+        np.savez_compressed(os.path.join(OUT, f"ocsort_{name}.npz"), dets=packed, dets_per_frame=n_per, out=rows, out_per_frame=counts,
+                            thresh=np.float64(thresh), alive=np.int32(alive), **{f"kw_{k}": np.float64(v) for k, v in tkw.items()})
+        print(name, "frames", len(frames), "dets", nz, "track rows", len(rows), "ids", len(set(rows[:, 4])) if len(rows) else 0, "alive", alive)
