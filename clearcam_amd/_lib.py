@@ -14,7 +14,7 @@ SYMBOLS = [
     "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_destroy", "cc_conv2d_nhwc",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
     "cc_clip_last_gpu_ms", "cc_clip_destroy", "cc_crop_preprocess",
-    "cc_ocsort_create", "cc_ocsort_update", "cc_ocsort_num_tracks", "cc_ocsort_destroy",
+    "cc_ocsort_create", "cc_ocsort_update", "cc_ocsort_update_many", "cc_ocsort_num_tracks", "cc_ocsort_destroy",
     "cc_index_create", "cc_index_add", "cc_index_size", "cc_index_scores", "cc_index_search", "cc_index_destroy",
 ]
 
@@ -39,6 +39,12 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise CCError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        # PyTorch-ROCm ships its own libamdhip64/libhsa-runtime64.  Whichever copy is mapped first serves the whole
+        # process (same SONAME), and torch fails to find the GPU on the system copy: let torch map its runtime first.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.cc_last_error.restype = C.c_char_p
     vp, ip, fp, i64p = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int64)
@@ -63,6 +69,7 @@ def lib() -> C.CDLL:
         "cc_crop_preprocess": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_ocsort_create": [C.POINTER(vp), C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int],
         "cc_ocsort_update": [vp, vp, C.c_int, C.c_double, vp, C.c_int, ip],
+        "cc_ocsort_update_many": [vp, C.c_int, vp, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int],
         "cc_ocsort_num_tracks": [vp, ip],
         "cc_index_create": [C.POINTER(vp), C.c_int, C.c_int64, C.c_int],
         "cc_index_add": [vp, vp, C.c_int64, C.c_int],

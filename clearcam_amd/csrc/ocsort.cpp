@@ -28,10 +28,14 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
 namespace cc { void set_error(const std::string& msg); }
+#ifndef OCP
+#define OCP(i)
+#endif
 
 namespace {
 
@@ -172,7 +176,7 @@ struct Track {
   bool has_obs = false;                          // last_observation is a real box (not the [-1]*5 placeholder)
   Box5 last{};
   std::vector<std::pair<int, Box5>> observations;   // age -> box, ages strictly increasing
-  std::vector<std::pair<int, double>> occurrences;  // class id -> summed score, insertion ordered
+  std::vector<std::pair<int, float>> occurrences;   // class id -> summed score (float32 sums, as numpy 2 adds them), insertion ordered
   int class_id = 0;
   float score = 0.f;
   double velocity[2] = {0, 0};                   // (dy, dx) unit direction, float32 values once set
@@ -194,13 +198,13 @@ struct Track {
     for (auto it = observations.rbegin(); it != observations.rend(); ++it) { if (it->first == a) return &it->second; if (it->first < a) break; }
     return nullptr;
   }
-  void add_occurrence(int cls, double w) {
+  void add_occurrence(int cls, float w) {
     for (auto& o : occurrences) if (o.first == cls) { o.second += w; return; }
     occurrences.emplace_back(cls, w);
   }
   void update(const Box5* b, float sc, int cls) {            // ocsort.py:107-148
     if (!b) { kf.update(nullptr); return; }
-    add_occurrence(cls, (double)sc);
+    add_occurrence(cls, sc);
     {                                                        // max(dict, key=dict.get): first key holding the maximum
       size_t best = 0;
       for (size_t i = 1; i < occurrences.size(); ++i) if (occurrences[i].second > occurrences[best].second) best = i;
@@ -258,26 +262,109 @@ inline double iou_f32_f64(const float* d, const double* t) {             // asso
   return wh / ((double)a1 + a2 - wh);
 }
 
-// greedy assignment on ascending cost (association.py:32-52); NaN sorts last as in numpy
+// greedy assignment on ascending cost (association.py:32-52): walk the pairs in the order of a stable argsort (ties in
+// row-major order, NaN last as numpy sorts them) and take every pair whose row and column are still free; stop once all
+// rows or all columns are used.  The walk normally ends after a small prefix, so the order is produced lazily from a
+// heap on the total order (cost, index) instead of sorting all rows*cols pairs.
 void greedy_assign(const std::vector<double>& cost, int rows, int cols, std::vector<std::pair<int, int>>& out) {
   out.clear();
   if (rows == 0 || cols == 0) return;
-  std::vector<int> order(cost.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+  auto after = [&](int a, int b) {                     // true if a comes after b in the argsort order
     const double ca = cost[a], cb = cost[b];
-    if (std::isnan(ca)) return false;
-    if (std::isnan(cb)) return true;
-    return ca < cb;
-  });
+    const bool na = std::isnan(ca), nb = std::isnan(cb);
+    if (na || nb) return na != nb ? na : a > b;
+    if (ca != cb) return ca > cb;
+    return a > b;
+  };
+  std::vector<int> heap(cost.size());
+  for (size_t i = 0; i < heap.size(); ++i) heap[i] = (int)i;
+  std::make_heap(heap.begin(), heap.end(), after);
   std::vector<char> ru(rows, 0), cu(cols, 0);
   int nr = 0, nc = 0;
-  for (int f : order) {
-    const int r = f / cols, c = f - r * cols;
+  auto end = heap.end();
+  while (end != heap.begin()) {
+    std::pop_heap(heap.begin(), end, after); --end;
+    const int f = *end, r = f / cols, c = f - r * cols;
     if (ru[r] || cu[c]) continue;
     out.emplace_back(r, c);
     ru[r] = cu[c] = 1; ++nr; ++nc;
     if (nr == rows || nc == cols) break;
+  }
+}
+
+// The same walk for the first association, where the cost -(iou + angle term) would need a sqrt and an acos for each
+// of the dets x tracks pairs, and a crowded scene has tens of thousands of overlapping pairs.
+// |angle term| <= bound[row] = 0.5*|inertia|*score, so
+//  * a pair with IoU exactly 0 costs between -bmax and +bmax: every pair below -bmax has a non-zero IoU;
+//  * -(iou + bound[row]) is a lower bound of a pair's cost that needs no transcendental.
+// Phase 1 walks the pairs below -bmax in exact argsort order.  Each row keeps its candidates in a small heap keyed on
+// the lower bound, and a heap over the row heads yields the global minimum.  A pair is priced exactly only when it
+// surfaces with its row and column still free, and goes back under its exact cost (a priced entry on top is the true
+// minimum because every other key is a lower bound; unpriced entries win key ties so that an equal-cost pair with a
+// smaller index is never overtaken).  When a row is assigned, the rest of its candidates are dropped unseen.
+// Phase 2: whatever the walk does afterwards only involves rows and columns that are still free, so only that block is
+// priced and sorted.  The assignment sequence is the one a stable argsort of the dense cost matrix gives.
+struct Cand { double c; int idx; bool exact; };
+inline bool cand_after(const Cand& a, const Cand& b) {       // heap order: true if a must come out after b
+  if (a.c != b.c) return a.c > b.c;
+  if (a.exact != b.exact) return a.exact;
+  return a.idx > b.idx;
+}
+
+template <class CostFn>
+void greedy_first(std::vector<std::vector<Cand>>& rowc, int rows, int cols, double bmax, CostFn cost,
+                  std::vector<std::pair<int, int>>& out) {
+  out.clear();
+  if (rows == 0 || cols == 0) return;
+  std::vector<Cand> heads;                                   // one entry per row with candidates: its current minimum
+  for (int r = 0; r < rows; ++r) {
+    std::vector<Cand>& v = rowc[r];
+    if (v.empty()) continue;
+    std::make_heap(v.begin(), v.end(), cand_after);
+    heads.push_back(v.front());
+  }
+  std::make_heap(heads.begin(), heads.end(), cand_after);
+  std::vector<char> ru(rows, 0), cu(cols, 0);
+  int nr = 0, nc = 0;
+  while (!heads.empty()) {
+    std::pop_heap(heads.begin(), heads.end(), cand_after);
+    const Cand it = heads.back(); heads.pop_back();
+    const int r = it.idx / cols, c = it.idx - r * cols;
+    std::vector<Cand>& v = rowc[r];                          // `it` is v.front()
+    std::pop_heap(v.begin(), v.end(), cand_after); v.pop_back();
+    bool row_done = false;
+    if (!cu[c]) {
+      if (!it.exact) {
+        const double k = cost(r, c);
+        if (k < -bmax) { v.push_back(Cand{k, it.idx, true}); std::push_heap(v.begin(), v.end(), cand_after); }
+      } else {
+        out.emplace_back(r, c);
+        ru[r] = cu[c] = 1; ++nr; ++nc;
+        if (nr == rows || nc == cols) return;
+        row_done = true;
+      }
+    }
+    if (!row_done && !v.empty()) { heads.push_back(v.front()); std::push_heap(heads.begin(), heads.end(), cand_after); }
+  }
+  std::vector<int> fr, fc;
+  for (int r = 0; r < rows; ++r) if (!ru[r]) fr.push_back(r);
+  for (int c = 0; c < cols; ++c) if (!cu[c]) fc.push_back(c);
+  struct Tail { double c; int idx; };
+  std::vector<Tail> items;
+  items.reserve(fr.size() * fc.size());
+  for (int r : fr) for (int c : fc) items.push_back(Tail{cost(r, c), r * cols + c});
+  std::sort(items.begin(), items.end(), [](const Tail& a, const Tail& b) {
+    const bool na = std::isnan(a.c), nb = std::isnan(b.c);
+    if (na || nb) return na != nb ? nb : a.idx < b.idx;
+    if (a.c != b.c) return a.c < b.c;
+    return a.idx < b.idx;
+  });
+  for (const Tail& it : items) {
+    const int r = it.idx / cols, c = it.idx - r * cols;
+    if (ru[r] || cu[c]) continue;
+    out.emplace_back(r, c);
+    ru[r] = cu[c] = 1; ++nr; ++nc;
+    if (nr == rows || nc == cols) return;
   }
 }
 
@@ -296,6 +383,9 @@ struct cc_ocsort {
   double iou_threshold = 0.3, inertia = 0.2;
   int frame_count = 0, next_id = 0;
   std::vector<std::unique_ptr<Track>> tracks;
+  std::vector<std::vector<Cand>> cand_scratch;
+  std::vector<double> iou_scratch;      // dets x tracks matrix, kept between frames (a fresh 0.5 MB vector per frame
+                                        // per camera is an mmap/munmap pair and serialises the camera threads in the kernel)
 };
 
 namespace {
@@ -331,33 +421,71 @@ void ocsort_update(cc_ocsort& S, const float* rows, int n, double det_thresh, st
   if (T == 0) {
     for (int d = 0; d < D; ++d) um_d.push_back(d);
   } else {
-    std::vector<double> iou((size_t)D * T), cost((size_t)D * T);
-    for (int d = 0; d < D; ++d) {
-      const float cx1 = (dets[d].v[0] + dets[d].v[2]) / 2.f, cy1 = (dets[d].v[1] + dets[d].v[3]) / 2.f;
+    // IoU for every pair (cheap); the velocity-direction term needs sqrt + acos per pair and is evaluated only where the
+    // greedy walk can observe it (see greedy_first).
+    std::vector<double>& iou = S.iou_scratch;
+    iou.resize((size_t)D * T);
+    std::vector<std::vector<Cand>>& rowc = S.cand_scratch;   // per detection: pairs that can cost less than -bmax
+    if ((int)rowc.size() < D) rowc.resize(D);
+    std::vector<double> bound(D);                            // |angle term| <= 0.5*|inertia|*score
+    double bmax = 0.0;
+    for (int d = 0; d < D; ++d) { bound[d] = (0.5 * std::fabs(S.inertia)) * std::fabs((double)dets[d].v[4]); bmax = std::max(bmax, bound[d]); }
+    std::vector<int> rs(D, 0), cs(T, 0);                     // pairs above the IoU threshold per row / column
+    {
+      std::vector<double> a2(T); std::vector<char> tnan(T);
       for (int t = 0; t < T; ++t) {
-        const double* ko = &kobs[(size_t)t * 5];
-        const double cx2 = (ko[0] + ko[2]) / 2.0, cy2 = (ko[1] + ko[3]) / 2.0;
-        double dx = (double)cx1 - cx2, dy = (double)cy1 - cy2;
+        const double* b = &trks[(size_t)t * 4];
+        a2[t] = (b[2] - b[0]) * (b[3] - b[1]);
+        tnan[t] = std::isnan(b[0]) || std::isnan(b[1]) || std::isnan(b[2]) || std::isnan(b[3]);
+      }
+      for (int d = 0; d < D; ++d) {
+        const float* v = dets[d].v;
+        const double x1 = v[0], y1 = v[1], x2 = v[2], y2 = v[3];
+        const double a1 = (double)((v[2] - v[0]) * (v[3] - v[1]));       // float32 product, as numpy computes it
+        double* row = &iou[(size_t)d * T];
+        std::vector<Cand>& rc = rowc[d];
+        rc.clear();
+        for (int t = 0; t < T; ++t) {
+          const double* b = &trks[(size_t)t * 4];
+          const double w = std::min(x2, b[2]) - std::max(x1, b[0]), h = std::min(y2, b[3]) - std::max(y1, b[1]);
+          // disjoint boxes with a positive area sum: 0 / positive = 0 exactly, skip the division (most pairs)
+          if ((w <= 0.0 || h <= 0.0) && !tnan[t] && a1 + a2[t] > 0.0) { row[t] = 0.0; continue; }
+          const double o = iou_f32_f64(v, b);
+          row[t] = o;
+          if (o > S.iou_threshold) { ++rs[d]; ++cs[t]; }
+          if (o != 0.0 && !std::isnan(o)) {                  // zero IoU cannot be below -bmax; NaN sorts last (phase 2)
+            const double lb = -(o + bound[d]);
+            if (lb < -bmax) rc.push_back(Cand{lb, d * T + t, false});
+          }
+        }
+      }
+    }
+    std::vector<float> dcx(D), dcy(D);
+    for (int d = 0; d < D; ++d) { dcx[d] = (dets[d].v[0] + dets[d].v[2]) / 2.f; dcy[d] = (dets[d].v[1] + dets[d].v[3]) / 2.f; }
+    auto pair_cost = [&](int d, int t) -> double {           // -(iou + angle_diff_cost)  (association.py:58-82)
+      const double* ko = &kobs[(size_t)t * 5];
+      const double cx2 = (ko[0] + ko[2]) / 2.0, cy2 = (ko[1] + ko[3]) / 2.0;
+      const double valid = ko[4] < 0 ? 0.0 : 1.0;
+      double adc;
+      if ((valid == 0.0 || (vel[t * 2] == 0.0 && vel[t * 2 + 1] == 0.0)) && std::isfinite(cx2) && std::isfinite(cy2)) {
+        adc = 0.0;                                           // acos(0) is exactly pi/2 in double: the angle term is exactly 0
+      } else {
+        double dx = (double)dcx[d] - cx2, dy = (double)dcy[d] - cy2;
         const double norm = std::sqrt(dx * dx + dy * dy) + 1e-6;
         dx /= norm; dy /= norm;
         double c = vel[t * 2 + 1] * dx + vel[t * 2] * dy;
         c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);           // np.clip (NaN passes through)
         const double ang = (kPi / 2.0 - std::fabs(std::acos(c))) / kPi;
-        const double valid = ko[4] < 0 ? 0.0 : 1.0;
-        const double adc = ((valid * ang) * S.inertia) * (double)dets[d].v[4];
-        const double o = iou_f32_f64(dets[d].v, &trks[(size_t)t * 4]);
-        iou[(size_t)d * T + t] = o;
-        cost[(size_t)d * T + t] = -(o + adc);
+        adc = ((valid * ang) * S.inertia) * (double)dets[d].v[4];
       }
-    }
+      return -(iou[(size_t)d * T + t] + adc);
+    };
     std::vector<std::pair<int, int>> cand;
     if (D > 0) {
-      std::vector<int> rs(D, 0), cs(T, 0);
-      for (int d = 0; d < D; ++d) for (int t = 0; t < T; ++t) if (iou[(size_t)d * T + t] > S.iou_threshold) { ++rs[d]; ++cs[t]; }
       if (*std::max_element(rs.begin(), rs.end()) == 1 && *std::max_element(cs.begin(), cs.end()) == 1) {
         for (int d = 0; d < D; ++d) for (int t = 0; t < T; ++t) if (iou[(size_t)d * T + t] > S.iou_threshold) cand.emplace_back(d, t);
       } else {
-        greedy_assign(cost, D, T, cand);
+        greedy_first(rowc, D, T, bmax, pair_cost, cand);
       }
     }
     std::vector<char> dm(D, 0), tm(T, 0);
@@ -430,7 +558,7 @@ void ocsort_update(cc_ocsort& S, const float* rows, int n, double det_thresh, st
     for (int i = 0; i < 4; ++i) k->kf.x[i] = z.v[i];
     k->id = S.next_id++;
     k->class_id = cls[d]; k->score = dets[d].v[4];
-    k->add_occurrence(cls[d], 1.0);
+    k->add_occurrence(cls[d], 1.0f);
     S.tracks.push_back(std::move(k));
   }
 
@@ -476,6 +604,38 @@ int cc_ocsort_update(cc_ocsort* h, const float* dets, int n, double det_thresh, 
   *n_out = m;
   if (m > cap) throw std::length_error("cc_ocsort_update: output capacity too small (state already advanced)");
   if (m) std::memcpy(out, rows.data(), rows.size() * sizeof(double));
+  CC_API_END
+}
+
+// One frame for each of `count` cameras in one call: camera c reads rows_per rows at dets + c*rows_per*6 and writes
+// at most cap_per rows at out + c*cap_per*9.  Cameras are independent, so they are spread over n_threads host threads.
+int cc_ocsort_update_many(cc_ocsort* const* hs, int count, const float* dets, int rows_per, double det_thresh, double* out,
+                          int cap_per, int* n_out, int n_threads) {
+  CC_API_BEGIN
+  if (!hs || count < 0 || rows_per < 0 || (rows_per > 0 && !dets) || !out || cap_per <= 0 || !n_out)
+    throw std::invalid_argument("cc_ocsort_update_many: bad argument");
+  for (int c = 0; c < count; ++c) if (!hs[c]) throw std::invalid_argument("cc_ocsort_update_many: null tracker");
+  std::vector<std::string> errs(count);
+  auto work = [&](int lo, int hi) {
+    std::vector<double> rows;
+    for (int c = lo; c < hi; ++c) {
+      try {
+        ocsort_update(*hs[c], dets + (size_t)c * rows_per * 6, rows_per, det_thresh, rows);
+        const int m = (int)(rows.size() / 9);
+        n_out[c] = m;
+        if (m > cap_per) { errs[c] = "output capacity too small"; continue; }
+        if (m) std::memcpy(out + (size_t)c * cap_per * 9, rows.data(), rows.size() * sizeof(double));
+      } catch (const std::exception& e) { errs[c] = e.what(); }
+    }
+  };
+  const int nt = std::max(1, std::min(n_threads, count));
+  if (nt == 1) work(0, count);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, (int)((long)count * t / nt), (int)((long)count * (t + 1) / nt));
+    for (auto& t : th) t.join();
+  }
+  for (int c = 0; c < count; ++c) if (!errs[c].empty()) throw std::runtime_error("cc_ocsort_update_many: camera " + std::to_string(c) + ": " + errs[c]);
   CC_API_END
 }
 

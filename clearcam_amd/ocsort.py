@@ -74,6 +74,23 @@ class OCSort:
         return [STrack(tlwh=r[:4], score=r[7], class_id=r[6], track_id=r[4], age=r[5], speed=r[8])
                 for r in self.update_rows(output_results, det_thresh)]
 
+    @staticmethod
+    def update_many(trackers: "List[OCSort]", preds, det_thresh=0.25, n_threads: int = 8, cap: int = 512) -> List[np.ndarray]:
+        """One frame per camera in one native call: preds (N,300,6) float32 (detector batch output), trackers[i] <-> preds[i].
+        Returns per-camera (n_i,9) float64 rows (see update_rows)."""
+        p = np.ascontiguousarray(as_numpy(preds), dtype=np.float32)
+        N = len(trackers)
+        if p.ndim != 3 or p.shape[0] != N or p.shape[2] != 6:
+            raise ValueError(f"expected ({N},rows,6) detections, got {p.shape}")
+        hs = (C.c_void_p * N)(*[t._h for t in trackers])
+        out = np.empty((N, cap, 9), np.float64)
+        n = np.zeros(N, np.int32)
+        _lib.check(_lib.lib().cc_ocsort_update_many(hs, N, _lib.ptr(p), p.shape[1], float(det_thresh), _lib.ptr(out), cap,
+                                                    _lib.ptr(n), int(n_threads)))
+        for t in trackers:
+            t.frame_count += 1
+        return [out[i, :n[i]].copy() for i in range(N)]
+
     def num_tracks(self) -> int:
         n = C.c_int(0)
         _lib.check(_lib.lib().cc_ocsort_num_tracks(self._h, C.byref(n)))

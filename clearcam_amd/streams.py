@@ -1,0 +1,191 @@
+"""Many-camera driver: pinned frame rings -> async H2D -> batched letterbox + detect -> async D2H -> OC-SORT per camera.
+
+The reference runs one process per camera whose loop is `frame -> Tensor(frame) -> jit_infer(yolo) -> .numpy() ->
+tracker.update` (clearcam.py:247-279,583-585): one synchronous copy and one batch-1 inference per frame.  Here one
+process per GPU serves N cameras per step (BASELINE.json configs[3]: 1080p cameras, one camera -> one GPU):
+
+  decode thread / synthetic source  writes frames into a PINNED host ring per camera (no per-frame allocation)
+  copy stream                       N x hipMemcpyAsync ring slot -> slot of the device batch   (overlaps compute)
+  model stream                      letterbox (bit-exact u8 bilinear) + 144 convs + decode + top-300/NMS, one launch chain
+  copy back                         (N,300,6) float32 -> pinned host, async
+  host                              cc_ocsort_update_many: N independent trackers on worker threads, while the GPU
+                                    is already busy with the next batch (two batches in flight)
+
+No collective anywhere: cameras are independent.  There is no CPU fallback: the detector is the HIP library.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .ocsort import OCSort
+
+
+class SyntheticCamera:
+    """Stand-in for a camera's decode thread (clearcam.py:401-421): a pinned ring of pre-decoded BGR uint8 frames.
+    Seeded noise background plus a few moving rectangles so consecutive frames differ."""
+
+    def __init__(self, height: int = 1080, width: int = 1920, seed: int = 0, ring: int = 2, base: Optional[np.ndarray] = None):
+        import torch
+        rng = np.random.default_rng(seed)
+        if base is None:
+            base = rng.integers(0, 256, (height, width, 3), dtype=np.uint8)
+        self.frames = torch.empty((ring, height, width, 3), dtype=torch.uint8).pin_memory()
+        view = self.frames.numpy()
+        boxes = [(int(rng.integers(0, max(1, height - height // 4))), int(rng.integers(0, max(1, width - width // 6))),
+                  max(2, height // int(rng.integers(4, 9))), max(2, width // int(rng.integers(6, 14))),
+                  [int(c) for c in rng.integers(0, 256, 3)], int(rng.integers(-12, 13)), int(rng.integers(-12, 13))) for _ in range(4)]
+        for k in range(ring):
+            np.copyto(view[k], np.roll(base, seed * 37, axis=1) if seed else base)
+            for (y, x, h, w, col, vy, vx) in boxes:
+                yy = int(np.clip(y + vy * k, 0, height - h)); xx = int(np.clip(x + vx * k, 0, width - w))
+                view[k, yy:yy + h, xx:xx + w] = col
+        self.ring, self.t = ring, 0
+
+    def read(self):
+        """Next frame as a pinned (H,W,3) uint8 torch tensor (no copy)."""
+        f = self.frames[self.t % self.ring]
+        self.t += 1
+        return f
+
+
+class _Slot:
+    def __init__(self, n, h, w, dev):
+        import torch
+        self.frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+        self.out = torch.empty((n, 300, 6), dtype=torch.float32, device=dev)
+        self.host_out = torch.empty((n, 300, 6), dtype=torch.float32).pin_memory()
+        self.up, self.done = torch.cuda.Event(), torch.cuda.Event()
+        self.t_submit = 0.0
+
+
+class StreamPipeline:
+    """N cameras -> one GPU.  submit(frames) queues upload + detect + download; collect() waits for the oldest batch in
+    flight and advances the N trackers.  Keep <= depth batches in flight (run() does)."""
+
+    def __init__(self, model, n_cams: int, frame_hw=(1080, 1920), depth: int = 2, det_thresh: float = 0.25,
+                 tracker_kwargs: Optional[dict] = None, n_threads: Optional[int] = None, track: bool = True):
+        import torch
+        self.torch = torch
+        self.model, self.n, self.hw, self.depth = model, n_cams, tuple(frame_hw), depth
+        self.dev = torch.device("cuda", model.device)
+        self.copy_stream, self.compute_stream = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self.slots = [_Slot(n_cams, frame_hw[0], frame_hw[1], self.dev) for _ in range(depth)]
+        if n_threads is None:
+            try:
+                n_threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                n_threads = os.cpu_count() or 1
+            n_threads = max(1, min(32, n_threads, n_cams))
+        self.det_thresh, self.n_threads, self.track = det_thresh, n_threads, track
+        self.trackers = [OCSort(**(tracker_kwargs or {"max_age": 100})) for _ in range(n_cams)]   # clearcam.py:239
+        self.submitted = self.collected = 0
+        self.track_s = 0.0
+        self.n_dets = 0
+        self.latency: List[float] = []
+
+    def submit(self, frames: Optional[Sequence] = None) -> None:
+        """frames: one pinned (H,W,3) uint8 host tensor per camera; None = re-run the frames already resident in the slot."""
+        torch = self.torch
+        if self.submitted - self.collected >= self.depth:
+            raise RuntimeError("too many batches in flight: call collect() first")
+        s = self.slots[self.submitted % self.depth]
+        s.t_submit = time.perf_counter()
+        if frames is not None:
+            if len(frames) != self.n:
+                raise ValueError(f"expected {self.n} frames, got {len(frames)}")
+            with torch.cuda.stream(self.copy_stream):
+                for i, f in enumerate(frames):
+                    s.frames[i].copy_(f, non_blocking=True)
+                s.up.record(self.copy_stream)
+            self.compute_stream.wait_event(s.up)
+        with torch.cuda.stream(self.compute_stream):
+            self.model.detect_batch_device(s.frames, s.out)
+            s.host_out.copy_(s.out, non_blocking=True)
+            s.done.record(self.compute_stream)
+        self.submitted += 1
+
+    def collect(self):
+        """-> (preds (N,300,6) float32 ndarray view valid until the slot is reused, per-camera track rows or None)."""
+        if self.collected >= self.submitted:
+            raise RuntimeError("nothing in flight")
+        s = self.slots[self.collected % self.depth]
+        s.done.synchronize()
+        preds = s.host_out.numpy()
+        rows = None
+        self.n_dets += int((preds[..., 4] > np.float32(self.det_thresh)).sum())
+        if self.track:
+            t0 = time.perf_counter()
+            rows = OCSort.update_many(self.trackers, preds, self.det_thresh, self.n_threads)
+            self.track_s += time.perf_counter() - t0
+        self.latency.append(time.perf_counter() - s.t_submit)
+        self.collected += 1
+        return preds, rows
+
+    def run(self, cameras: Optional[List[SyntheticCamera]], n_batches: int, warmup: int = 2) -> Dict[str, float]:
+        """Steady-state loop over n_batches (+warmup) batches; cameras=None benchmarks with frames resident in HBM."""
+        torch = self.torch
+        grab = (lambda: [c.read() for c in cameras]) if cameras is not None else (lambda: None)
+        if cameras is None:
+            for s in self.slots:                                  # something to detect on
+                s.frames.random_(0, 256)
+        for _ in range(warmup):
+            self.submit(grab()); self.collect()
+        torch.cuda.synchronize(self.dev)
+        self.track_s, self.latency, self.n_dets = 0.0, [], 0
+        t0 = time.perf_counter()
+        self.submit(grab())
+        for _ in range(n_batches - 1):
+            self.submit(grab())
+            self.collect()
+        self.collect()
+        dt = time.perf_counter() - t0
+        frames = n_batches * self.n
+        nbytes = self.n * self.hw[0] * self.hw[1] * 3
+        lat = sorted(self.latency)
+        return {"cameras": self.n, "frame_hw": list(self.hw), "batches": n_batches, "frames_per_sec": frames / dt,
+                "fps_per_camera": frames / dt / self.n, "ms_per_batch": dt / n_batches * 1e3,
+                "h2d_GBps": (nbytes * n_batches / dt / 1e9) if cameras is not None else 0.0,
+                "tracker_ms_per_batch": self.track_s / n_batches * 1e3, "latency_ms_p50": lat[len(lat) // 2] * 1e3,
+                "latency_ms_max": lat[-1] * 1e3, "frames_resident": cameras is None,
+                "det_thresh": self.det_thresh, "dets_above_thresh_per_frame": self.n_dets / frames,
+                "tracks_alive": int(sum(t.num_tracks() for t in self.trackers)), "tracker_threads": self.n_threads}
+
+    def close(self):
+        for t in self.trackers:
+            t.close()
+
+
+def make_cameras(n: int, height: int = 1080, width: int = 1920, ring: int = 2, seed: int = 100) -> List[SyntheticCamera]:
+    base = np.random.default_rng(seed).integers(0, 256, (height, width, 3), dtype=np.uint8)
+    return [SyntheticCamera(height, width, seed=i, ring=ring, base=base) for i in range(n)]
+
+
+def main() -> None:
+    import argparse
+    import json
+    from .weights import shift_class_bias, synthetic_yolov9_state_dict
+    from .yolov9 import YOLOv9
+    ap = argparse.ArgumentParser(description="N synthetic 1080p cameras -> detect -> OC-SORT on one GPU")
+    ap.add_argument("--cams", type=int, default=8)
+    ap.add_argument("--batches", type=int, default=30)
+    ap.add_argument("--size", default="c")
+    ap.add_argument("--res", type=int, default=640)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--resident", action="store_true", help="frames stay in HBM (no PCIe upload)")
+    ap.add_argument("--thresh", type=float, default=0.25, help="tracker score threshold (clearcam's detection threshold setting)")
+    ap.add_argument("--cls-bias-shift", type=float, default=0.0, help="move the synthetic class-logit biases (sparser detections)")
+    a = ap.parse_args()
+    model = YOLOv9(a.size, a.res, state_dict=shift_class_bias(synthetic_yolov9_state_dict(a.size, 1234), a.cls_bias_shift), dtype=a.dtype)
+    pipe = StreamPipeline(model, a.cams, (a.height, a.width), det_thresh=a.thresh)
+    cams = None if a.resident else make_cameras(a.cams, a.height, a.width)
+    print(json.dumps(pipe.run(cams, a.batches)))
+
+
+if __name__ == "__main__":
+    main()

@@ -170,6 +170,17 @@ def synthetic_yolov9_state_dict(size: str = "c", seed: int = 1234, scales=None) 
     return sd
 
 
+def shift_class_bias(sd: Dict[str, np.ndarray], shift: float) -> Dict[str, np.ndarray]:
+    """Copy of a YOLOv9 state dict with every class-logit bias moved by `shift`.  The seeded weights fire on ~260
+    anchors of a noise frame (good for top-k/NMS parity); a negative shift gives the sparse detections of a real
+    scene for tracker-facing benchmarks without changing a single FLOP of the detector."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if ".cv3." in k and k.endswith(".2.bias") and v.shape == (80,):
+            out[k] = (v + np.float32(shift)).astype(np.float32)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # CLIP
 # ----------------------------------------------------------------------------------------------

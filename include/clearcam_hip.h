@@ -107,6 +107,10 @@ int cc_crop_preprocess(const uint8_t* pixels, const int64_t* offsets, const int3
 typedef struct cc_ocsort cc_ocsort;
 int cc_ocsort_create(cc_ocsort** h, int max_age, int min_hits, double iou_threshold, int delta_t, double inertia, int use_byte);
 int cc_ocsort_update(cc_ocsort* h, const float* dets, int n, double det_thresh, double* out, int cap, int* n_out);
+/* One frame for each of `count` cameras: camera c reads rows_per rows at dets + c*rows_per*6 (e.g. the (B,300,6) detector
+ * output as is) and writes n_out[c] <= cap_per rows at out + c*cap_per*9; cameras run on up to n_threads host threads. */
+int cc_ocsort_update_many(cc_ocsort* const* hs, int count, const float* dets, int rows_per, double det_thresh, double* out,
+                          int cap_per, int* n_out, int n_threads);
 int cc_ocsort_num_tracks(cc_ocsort* h, int* n);
 void cc_ocsort_destroy(cc_ocsort* h);
 
