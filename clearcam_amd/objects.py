@@ -239,6 +239,33 @@ class ObjectFinder:
         for k in set(target) - valid:
             del target[k]
 
+    # -- append-only store (clearcam_amd/store.py) instead of one pickle per folder ---------------------------
+    def attach_store(self, capacity: Optional[int] = None) -> int:
+        """Load every stored crop under base_path (store files and/or the reference's pickles) straight into the device
+        matrix: no per-crop dict entries, one H2D copy.  Subsequent `search` calls scan it; `add_embedding` appends.
+        Returns the number of rows."""
+        from .store import load_all
+        paths, rows = load_all(self.base_path, 768)
+        if self._index is not None:
+            self._index.close()
+        dim = rows.shape[1] if len(paths) else 768
+        self._index = EmbeddingIndex(dim, max(capacity or 0, 2 * len(paths), 1024), device=self.model.device if self.model else 0)
+        if len(paths):
+            self._index.add(rows)
+        self._index_paths, self._index_src, self._attached = list(paths), "store", True
+        return len(paths)
+
+    def add_embedding(self, path: str, emb) -> None:
+        """What clearcam.py:1282-1287 does per crop (load pickle, insert, rewrite pickle) as one appended row: on disk in
+        the crop's day folder, in the dict the reference exposes, and in the attached device matrix."""
+        from .store import EmbeddingStore
+        e = np.asarray(as_numpy(emb), np.float32).reshape(1, -1)
+        EmbeddingStore(os.path.dirname(path), e.shape[1]).append([path], e)
+        self.image_embeddings[path] = e
+        if getattr(self, "_attached", False):
+            self._index.add(e)
+            self._index_paths.append(path)
+
     def _device_index(self, embeddings: Dict[str, np.ndarray]) -> EmbeddingIndex:
         """(Re)build the HBM-resident matrix when the dict changed (the reference reloads before every search)."""
         sig = (id(embeddings), len(embeddings))
@@ -256,13 +283,14 @@ class ObjectFinder:
     # -- search (:356-390) ------------------------------------------------------------------------------
     def search(self, query=None, top_k=10, cam_name=None, timestamp=None, text_embedding=None, is_face=False):
         embeddings = self.face_embeddings if is_face else self.image_embeddings
-        if not embeddings:
+        attached = getattr(self, "_attached", False) and not is_face and len(self._index_paths) > 0
+        if not embeddings and not attached:
             print("No embeddings available.")
             return []
         if text_embedding is None:
             text_embedding = self.model._encode_text(query).numpy()
         q = np.asarray(as_numpy(text_embedding), np.float32).reshape(-1)
-        index = self._device_index(embeddings)
+        index = self._index if attached else self._device_index(embeddings)
         scores = index.scores(q)[0]                         # one HBM pass instead of a Python loop of N dot products
         sims = []
         for path, sim in zip(self._index_paths, scores):

@@ -166,3 +166,38 @@ def test_crops_to_embeddings_chain(tiny):
     m.precompute_embedding_device(x, emb)
     ref = o.precompute_embedding(np.stack([preprocess(c, CLIP_TINY.image_size) for c in crops]))
     assert np.abs(emb.cpu().numpy() - ref).max() < 1e-5
+
+
+def test_store_backed_search_matches_reference_loop(tmp_path):
+    """ObjectFinder over the append-only store (attach_store + add_embedding) == the reference's dict + Python loop."""
+    import pickle
+    from clearcam_amd.objects import ObjectFinder
+    rng = np.random.default_rng(9)
+    base = tmp_path / "cameras"
+    ref_store = {}
+    f = ObjectFinder(base_path=str(base))
+    def emb():
+        v = rng.standard_normal(768).astype(np.float32)
+        return (v / np.linalg.norm(v))[None]
+    # half of the history exists as reference pickles, the rest is appended crop by crop
+    d0 = base / "front" / "objects" / "2026-01-01"
+    d0.mkdir(parents=True)
+    old = {f"{d0}/{100 + i}.0_{i % 7}_{i % 3}.jpg": emb() for i in range(60)}
+    with open(d0 / "embeddings.pkl", "wb") as fh:
+        pickle.dump({"embeddings": old}, fh)
+    ref_store.update(old)
+    assert f.attach_store() == 60
+    for i in range(80):
+        cam, day = ("back", "2026-01-02") if i % 2 else ("front", "2026-01-01")
+        p = str(base / cam / "objects" / day / f"{500 + i}.0_{i % 11}_{i % 4}.jpg")
+        e = emb()
+        f.add_embedding(p, e)
+        ref_store[p] = e
+    q = emb()[0]
+    for kw in ({}, {"cam_name": "back"}, {"timestamp": "2026-01-01"}, {"top_k": 5}):
+        got, ref = f.search(text_embedding=q, **kw), search_reference(ref_store, q, **kw)
+        assert [p for p, _ in got] == [p for p, _ in ref]
+        assert np.allclose([s for _, s in got], [s for _, s in ref], atol=1e-6)
+    g = ObjectFinder(base_path=str(base))                        # a fresh process finds everything on disk
+    assert g.attach_store() == 140
+    assert [p for p, _ in g.search(text_embedding=q)] == [p for p, _ in search_reference(ref_store, q)]
