@@ -163,7 +163,7 @@ void launch_l2norm(const NormP& p, hipStream_t stream) {
 // Computing the TRANSPOSED scores puts one query per lane column (lane&15), so the softmax reduction is
 // 4*NF register values + two cross-lane steps, and the exponentiated P is already in MFMA B-operand layout.
 template <class T, int NF>    // NF = padded keys / 16
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   // two blocks per CU: one wave can run MFMAs while the other does its softmax
   constexpr int LP = NF * 16, VS = LP + 8;          // padded keys, V^T row stride (elements)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* ldsK = reinterpret_cast<uint4*>(smem);                         // [LP][8 chunks]
@@ -206,26 +206,36 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnP p) {
         const int row = f * 16 + ql;
         Mma<T>::run(ldsK[row * 8 + ((ks * 4 + g) ^ ((row >> 1) & 7))], qf[ks], s[f]);
       }
+      if (f % 3 == 2) asm volatile("" ::: "memory");         // keep at most 6 K fragments in flight: hoisting all 36 reads costs 144 VGPRs
     }
-    // s[f][r] = <k_{16f+4g+r}, q_{ql}>
+    // s[f][r] = <k_{16f+4g+r}, q_{ql}>.  The softmax is the VALU-bound part of this kernel (72 values per lane against
+    // 72 MFMAs per tile), so it is kept to max / fma / v_exp_f32 / add per value: the row maximum is taken on the raw
+    // scores (scale > 0 keeps the order), scale*log2(e) is folded into one fma feeding the hardware exp2, and masking
+    // code runs only for fragments that actually contain padded or future keys.
+    const float c = p.scale * 1.4426950408889634f;
     float mx = -INFINITY;
   #pragma unroll
-    for (int f = 0; f < NF; ++f)
+    for (int f = 0; f < NF; ++f) {
+      if (p.causal || f * 16 + 16 > p.L) {                     // wave-uniform
   #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = f * 16 + g * 4 + r;
-        float v = s[f][r] * p.scale;
-        if (key >= p.L || (p.causal && key > q)) v = -INFINITY;
-        s[f][r] = v;
-        mx = fmaxf(mx, v);
+        for (int r = 0; r < 4; ++r) {
+          const int key = f * 16 + g * 4 + r;
+          if (key >= p.L || (p.causal && key > q)) s[f][r] = -INFINITY;
+        }
       }
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][r]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * c;
     float sum = 0.f;
   #pragma unroll
-    for (int f = 0; f < NF; ++f)
+    for (int f = 0; f < NF; ++f) {
+      if (f * 16 >= p.L) { s[f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }      // fragment of padding only: p = 0
   #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float e = __expf(s[f][r] - mx); s[f][r] = e; sum += e; }
+      for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], c, -mc)); s[f][r] = e; sum += e; }
+    }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
 
@@ -235,23 +245,21 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnP p) {
   #pragma unroll
     for (int f2 = 0; f2 < NF / 2; ++f2) {
       // B operand k-slot (g, j): j<4 -> key 32f2 + 4g + j, j>=4 -> key 32f2 + 16 + 4g + (j-4); V^T was staged in that order
-      alignas(16) T pk[8];
-  #pragma unroll
-      for (int r = 0; r < 4; ++r) { pk[r] = from_f32<T>(s[2 * f2][r]); pk[4 + r] = from_f32<T>(s[2 * f2 + 1][r]); }
-      const uint4 pf = *reinterpret_cast<const uint4*>(pk);
+      const uint4 pf = make_uint4(pack2<T>(s[2 * f2][0], s[2 * f2][1]), pack2<T>(s[2 * f2][2], s[2 * f2][3]),
+                                  pack2<T>(s[2 * f2 + 1][0], s[2 * f2 + 1][1]), pack2<T>(s[2 * f2 + 1][2], s[2 * f2 + 1][3]));
   #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const uint4 vf = *reinterpret_cast<const uint4*>(ldsVt + (d * 16 + ql) * VS + f2 * 32 + g * 8);
         Mma<T>::run(vf, pf, o[d]);
       }
+      if (f2 & 1) asm volatile("" ::: "memory");
     }
     if (q < p.L) {
       const float inv = 1.0f / sum;
       T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q) * p.D + h * 64;
   #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        alignas(8) T t4[4] = {from_f32<T>(o[d][0] * inv), from_f32<T>(o[d][1] * inv), from_f32<T>(o[d][2] * inv), from_f32<T>(o[d][3] * inv)};
-        *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = *reinterpret_cast<uint2*>(t4);
+        *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = make_uint2(pack2<T>(o[d][0] * inv, o[d][1] * inv), pack2<T>(o[d][2] * inv, o[d][3] * inv));
       }
     }
   }
