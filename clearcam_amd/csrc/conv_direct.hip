@@ -98,6 +98,68 @@ __global__ __launch_bounds__(256) void pool_vec_kernel(const PoolP p) {
   *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
 }
 
+// ADown's second branch (detection/yolov9.py:47-51): avg_pool2d(2, stride 1) followed by max_pool2d(3, stride 2, pad 1)
+// on the same channels, in one pass: out(ho,wo) = max over the 3x3 window of pooled positions (2ho-1+r, 2wo-1+s) inside
+// [0,H-2]x[0,W-2] of the 2x2 average there.  The full-resolution averaged tensor is never written or read back.
+// Each average is summed in the order of the unfused kernel and rounding to T is monotone, so max-then-round gives
+// exactly what round-then-max gave.  The 4x4 input window lives in registers (two rows at a time).
+template <class T>
+__global__ __launch_bounds__(256) void avgmax_pool_kernel(const PoolP p) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int CV = p.C / E;
+  const size_t total = (size_t)p.B * p.Ho * p.Wo * CV;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % CV);
+  const size_t m = idx / CV;
+  const int hw = p.Ho * p.Wo;
+  const int b = (int)(m / hw), rem = (int)(m - (size_t)b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
+  const T* in = reinterpret_cast<const T*>(p.in) + p.in_coff + cv * E;
+  const int i0 = 2 * ho - 1, j0 = 2 * wo - 1;               // top-left input pixel of the 4x4 window
+  float prev[4][E], cur[4][E], acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = -INFINITY;
+  auto load_row = [&](int i, float (&row)[4][E]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = j0 + c;
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if ((unsigned)i < (unsigned)p.H && (unsigned)j < (unsigned)p.W)
+        u = *reinterpret_cast<const uint4*>(in + ((size_t)(b * p.H + i) * p.W + j) * p.in_cstride);
+      const T* t = reinterpret_cast<const T*>(&u);
+#pragma unroll
+      for (int e = 0; e < E; ++e) row[c][e] = to_f32<T>(t[e]);
+    }
+  };
+  load_row(i0, prev);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    load_row(i0 + r + 1, cur);
+    const int ph = i0 + r;                                   // pooled row: averages input rows ph, ph+1
+    if (ph >= 0 && ph <= p.H - 2) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int pw = j0 + s;
+        if (pw < 0 || pw > p.W - 2) continue;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float a = (((prev[s][e] + prev[s + 1][e]) + cur[s][e]) + cur[s + 1][e]) * 0.25f;
+          acc[e] = fmaxf(acc[e], a);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < E; ++e) prev[c][e] = cur[c][e];
+  }
+  uint4 o;
+  T* t = reinterpret_cast<T*>(&o);
+#pragma unroll
+  for (int e = 0; e < E; ++e) t[e] = from_f32<T>(acc[e]);
+  *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
+}
+
 // Scalar fallback: one thread per (pixel, channel), any channel count / alignment.
 template <class T>
 __global__ __launch_bounds__(256) void pool_kernel(const PoolP p) {
@@ -128,7 +190,11 @@ template <class T> static void launch_pool_t(const PoolP& p, hipStream_t stream)
   constexpr int E = 16 / (int)sizeof(T);
   const bool vec = p.C % E == 0 && p.in_coff % E == 0 && p.in_cstride % E == 0 && p.out_coff % E == 0 && p.out_cstride % E == 0 &&
                    ((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.out & 15) == 0;
-  if (vec) {
+  if (p.mode == 2) {
+    CC_CHECK(vec && p.k == 3 && p.stride == 2 && p.pad == 1, "avg-max pool: needs 16-byte channel chunks, k=3 s=2 p=1");
+    const size_t total = (size_t)p.B * p.Ho * p.Wo * (p.C / E);
+    hipLaunchKernelGGL(avgmax_pool_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+  } else if (vec) {
     const size_t total = (size_t)p.B * p.Ho * p.Wo * (p.C / E);
     hipLaunchKernelGGL(pool_vec_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
   } else {

@@ -20,7 +20,8 @@ struct PoolP {
   int B, H, W, C;        // input dims / channels processed
   int Ho, Wo;
   int k, stride, pad;
-  int mode;              // 0 = avg (count_include_pad, pad must be 0), 1 = max (-inf padding)
+  int mode;              // 0 = avg (count_include_pad, pad must be 0), 1 = max (-inf padding),
+                         // 2 = avg 2x2 s1 p0 followed by max k s p (k,stride,pad describe the max stage; H,W are the raw input)
 };
 void launch_pool(int dt, const PoolP& p, hipStream_t stream);
 

@@ -206,7 +206,8 @@ struct Builder {
     q.in = (const void*)(intptr_t)in.buf; q.in_cstride = ib.C; q.in_coff = in.coff;
     q.out = (void*)(intptr_t)out.buf; q.out_cstride = ob.C; q.out_coff = out.coff;
     q.B = P->B; q.H = ib.H; q.W = ib.W; q.C = in.C; q.Ho = ob.H; q.Wo = ob.W; q.k = k; q.stride = stride; q.pad = pad; q.mode = mode;
-    CC_CHECK(in.C == out.C && ob.H == (ib.H + 2 * pad - k) / stride + 1 && ob.W == (ib.W + 2 * pad - k) / stride + 1, "pool view mismatch");
+    const int ph = mode == 2 ? ib.H - 1 : ib.H, pw = mode == 2 ? ib.W - 1 : ib.W;     // mode 2 pools the avg-pooled (H-1, W-1) map
+    CC_CHECK(in.C == out.C && ob.H == (ph + 2 * pad - k) / stride + 1 && ob.W == (pw + 2 * pad - k) / stride + 1, "pool view mismatch");
     P->ops.push_back(op);
   }
 
@@ -252,17 +253,28 @@ struct Builder {
 
   View down(const std::string& p, View in, int cout) {   // ADown :40-52 / AConv :54-63
     const int H = P->bufs[in.buf].H, W = P->bufs[in.buf].W, C = in.C;
-    const int avg = new_buf(H - 1, W - 1, C);
-    pool(in, whole(avg), 2, 1, 0, 0);
     const int Ho = (H - 1 + 2 - 3) / 2 + 1, Wo = (W - 1 + 2 - 3) / 2 + 1;
     const int o = new_buf(Ho, Wo, cout);
     if (a.adown) {
       CC_CHECK(C == cout, "ADown keeps the channel count");
-      conv({{slice(whole(avg), 0, C / 2), 0}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(o), 0, C / 2), 2, 1);
+      // x.avg_pool2d(2,1,0).chunk(2,1): only the half the strided conv reads is materialised at full resolution;
+      // the other half goes avg -> max-pool in one pass (avgmax_pool_kernel)
+      const int avg = new_buf(H - 1, W - 1, C / 2);
+      pool(slice(in, 0, C / 2), whole(avg), 2, 1, 0, 0);
+      conv({{whole(avg), 0}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(o), 0, C / 2), 2, 1);
       const int mp = new_buf(Ho, Wo, C / 2);
-      pool(slice(whole(avg), C / 2, C / 2), whole(mp), 3, 2, 1, 1);
+      const int E = Y->dtype == F32 ? 4 : 8;
+      if ((C / 2) % E == 0 && in.coff % E == 0 && P->bufs[in.buf].C % E == 0) {
+        pool(slice(in, C / 2, C / 2), whole(mp), 3, 2, 1, 2);
+      } else {                                               // channel counts off the 16-byte grid (yolov9-m): two passes
+        const int avg2 = new_buf(H - 1, W - 1, C / 2);
+        pool(slice(in, C / 2, C / 2), whole(avg2), 2, 1, 0, 0);
+        pool(whole(avg2), whole(mp), 3, 2, 1, 1);
+      }
       conv({{whole(mp), 0}}, pconv({p + ".cv2.conv"}, {1}), slice(whole(o), C / 2, C / 2), 1, 1);
     } else {
+      const int avg = new_buf(H - 1, W - 1, C);
+      pool(in, whole(avg), 2, 1, 0, 0);
       conv({{whole(avg), 0}}, pconv({p + ".cv1.conv"}, {1}), whole(o), 2, 1);
     }
     return whole(o);
