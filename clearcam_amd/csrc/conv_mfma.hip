@@ -103,6 +103,83 @@ template <int CPRW> __device__ __forceinline__ int swz(int row) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Epilogue shared by the conv kernels.  acc[j][i] = 4 consecutive output channels (n0 + wn0 + 16j + 4*(lane>>4) + e) of
+// tile pixel row = wm0 + 16i + (lane&15);  pix(row) -> flat output pixel index (b*Ho + ho)*Wo + wo, or -1 outside the image.
+// 16-bit outputs without residual go through LDS (chunk-swizzled, the K stages are dead by now) so that every pixel's BN
+// channels leave as 16-byte-per-lane, line-contiguous stores; f32 outputs / residual adds store from registers.
+template <class T, int BM, int BN, int WM, int MI, int NJ, class PixFn>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][MI], int n0, uint4* lds, PixFn pix) {
+  constexpr int NT = 2 * BM, WN = NT / 64 / WM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave % WM) * (BM / WM), wn0 = (wave / WM) * (BN / WN);
+  const int fr = lane & 15, fg = lane >> 4;
+  if constexpr (sizeof(T) == 2) {
+    constexpr int ROWB = BN * 2;                       // epilogue tile row (bytes), chunk-swizzled, no padding
+    constexpr int CPR = BN / 8;                        // 16-byte chunks per row
+    auto rowswz = [](int row) { if constexpr (CPR <= 16) return row / (16 / CPR); else return row * (CPR / 16); };
+    if (!p.res && !p.out_f32 && (p.Cout % 8 == 0) && (p.out_coff % 8 == 0) && (p.out_cstride % 8 == 0)) {
+      __syncthreads();                                 // every wave is done reading the K stages
+      char* tilep = reinterpret_cast<char*>(lds);
+      auto to_lds = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int nl = wn0 + j * 16 + fg * 4, n = n0 + nl;
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.bias && n < p.Cout) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const float v0 = activate<T, ACT>(acc[j][i][0] + b4.x), v1 = activate<T, ACT>(acc[j][i][1] + b4.y);
+            const float v2 = activate<T, ACT>(acc[j][i][2] + b4.z), v3 = activate<T, ACT>(acc[j][i][3] + b4.w);
+            const int row = wm0 + i * 16 + fr;
+            const int ch = (nl >> 3) ^ (rowswz(row) & (CPR - 1));
+            *reinterpret_cast<uint2*>(tilep + row * ROWB + ch * 16 + (nl & 4) * 2) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
+          }
+        }
+      };
+      if (p.act == 1) to_lds(std::integral_constant<int, 1>{});
+      else if (p.act == 2) to_lds(std::integral_constant<int, 2>{});
+      else to_lds(std::integral_constant<int, 0>{});
+      __syncthreads();
+      T* outp = reinterpret_cast<T*>(p.out) + p.out_coff + n0;
+#pragma unroll
+      for (int q = 0; q < BM * CPR / NT; ++q) {
+        const int idx = tid + NT * q, row = idx / CPR, ch = idx - row * CPR;
+        const long m = pix(row);
+        if (m >= 0 && n0 + ch * 8 < p.Cout)
+          *reinterpret_cast<uint4*>(outp + (size_t)m * p.out_cstride + ch * 8) =
+              *reinterpret_cast<const uint4*>(tilep + row * ROWB + (ch ^ (rowswz(row) & (CPR - 1))) * 16);
+      }
+      return;
+    }
+  }
+  // direct path: bias -> activation -> (+residual) -> store 4 consecutive channels of one pixel
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n0 + wn0 + j * 16 + fg * 4;
+    if (n >= p.Cout) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const long m = pix(wm0 + i * 16 + fr);
+      if (m < 0) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = activate_rt<T>(acc[j][i][e] + bv[e], p.act);
+      if (p.res) {
+        float rv[4];
+        const size_t ri = (size_t)m * p.res_cstride + p.res_coff + n;
+        if (p.res_f32) load4<float>(p.res, ri, rv); else load4<T>(p.res, ri, rv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
+      }
+      const size_t oi = (size_t)m * p.out_cstride + p.out_coff + n;
+      if (p.out_f32) store4<float>(p.out, oi, v); else store4<T>(p.out, oi, v);
+    }
+  }
+}
+
 // SIMPLE: one source, no upsample, ks <= 3 -> incremental row pointers.  !SIMPLE: general two-source / upsample path.
 // NS = LDS stages: the DMA of step t+NS-1 is issued while step t computes (prefetch distance NS-1 steps).
 // BM = pixels per tile (128 -> 4 waves, 256 -> 8 waves: half the L2->LDS weight traffic per flop).
@@ -292,70 +369,230 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
-  if constexpr (sizeof(T) == 2) {
-    constexpr int ROWB = BN * 2;                       // epilogue tile row (bytes), chunk-swizzled, no padding
-    constexpr int CPR = BN / 8;                        // 16-byte chunks per row
-    auto rowswz = [](int row) { if constexpr (CPR <= 16) return row / (16 / CPR); else return row * (CPR / 16); };
-    if (!p.res && !p.out_f32 && (p.Cout % 8 == 0) && (p.out_coff % 8 == 0) && (p.out_cstride % 8 == 0)) {
-      __syncthreads();                                 // every wave is done reading the K stages
-      char* tilep = reinterpret_cast<char*>(lds);
-      auto to_lds = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
+  conv_epilogue<T, BM, BN, WM, MI, NJ>(p, acc, n0, lds, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; });
+}
+
+// ---- 3x3 stride-1 convolution with the input halo tile resident in LDS ---------------------------------------------------
+// The implicit GEMM above stages a fresh 128-pixel x 64-channel slab for each of the nine taps: nine times the input bytes
+// through L2 -> LDS.  Bytes in flight per CU are capped by LDS capacity, so for the narrow layers (64..128 channels, where
+// the weight slab is small and the input slab dominates) that inflated traffic, not the MFMAs, sets the pace.
+// Here an output tile is 8 rows x 16 pixels and its 10 x 18 input patch (64 channels = one 128-byte row per pixel, same
+// chunk swizzle) is loaded ONCE per 64-channel slab; the nine taps read shifted windows of it (16 consecutive patch rows
+// at any offset still hit 16 distinct bank groups).  K order is (channel slab, tap) instead of (tap, channel slab).
+// Per K step only the BN x 64 weight slab streams in; pieces of the next slab's patch ride along in the first six taps.
+struct HaloAux { float inv_tiles, inv_tx; int tiles, tx, nt; };
+
+template <class T, int BN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvP p, const HaloAux a) {
+  constexpr int BM = 128, WM = 2, WN = 2, MI = 4, NJ = BN / WN / 16;
+  constexpr int PW = 18, PROWS = 184;                  // 10 x 18 = 180 patch pixels, padded to whole 8-row DMA groups
+  constexpr int XP = PROWS * 8, WS = BN * 8;           // uint4 per patch buffer / weight stage
+  constexpr int WR = BN / 32;                          // weight rows per thread per step
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  static_assert(2 * XP * 16 >= BM * BN * 2, "epilogue tile must fit in the patch buffers");
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [2][XP] patches, then [2][WS] weight stages
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned lds_base = lds_addr(lds);
+
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = wg / a.nt, n0 = (wg - mt * a.nt) * BN;
+  const int b = fdiv(mt, a.tiles, a.inv_tiles), trem = mt - b * a.tiles, ty = fdiv(trem, a.tx, a.inv_tx), tx = trem - ty * a.tx;
+  const int h0 = ty * 8, w0 = tx * 16;
+
+  // ---- loaders: thread -> (row within an 8-row group, 16-byte position); source chunk = position ^ swizzle(row)
+  const int ppos = tid & 7, prow = tid >> 3;           // prow 0..31; rows prow + 32*i
+  const char* xcur[6];                                 // patch rows prow + 32*i, i < 6 (wave 3 has no i = 5: rows >= 184)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int pr = prow + 32 * i;
+    const int py = pr / PW, px = pr - py * PW;
+    const int ih = h0 - 1 + py, iw = w0 - 1 + px;
+    const bool ok = pr < 180 && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+    const int chunk = ppos ^ swz<8>(pr);
+    xcur[i] = ok ? reinterpret_cast<const char*>(p.s0.ptr) +
+                       ((((long)b * p.s0.H + ih) * p.s0.W + iw) * (long)p.s0.cstride + p.s0.coff + chunk * 8) * (long)sizeof(T)
+                 : reinterpret_cast<const char*>(&g_zero16);
+  }
+  unsigned xinc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xinc[i] = xcur[i] == reinterpret_cast<const char*>(&g_zero16) ? 0u : 128u;
+  const char* wbase[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int row = prow + 32 * i, n = n0 + row;
+    const int chunk = ppos ^ swz<8>(row);
+    wbase[i] = n < p.Cout ? reinterpret_cast<const char*>(p.w) + ((size_t)n * p.Kw + chunk * 8) * sizeof(T) : nullptr;
+  }
+  auto issue_w = [&](int stage, int tap, int c0) {     // weight slab of (tap, channels c0..c0+63)
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(2 * XP + stage * WS + wave * 64) * 16u);
+    const long off = ((long)tap * p.Cin + c0) * (long)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+      glds16(wbase[i] ? static_cast<const void*>(wbase[i] + off) : static_cast<const void*>(&g_zero16), dst + i * (256 * 16u));
+  };
+  auto issue_x = [&](int buf, int i) {                 // 32 patch rows (one 8-row group per wave) of the current xcur slab
+    if (wave * 8 + 32 * i < PROWS) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * XP + (32 * i + wave * 8) * 8) * 16u);
+      glds16(xcur[i], dst);
+    }
+  };
+
+  const int wm = wave & 1, wn0 = (wave >> 1) * (BN / WN);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nch = p.Cin >> 6, nsteps = 9 * nch;
+
+  f32x4 acc[NJ][MI];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: patch of slab 0 and the first weight slab
+#pragma unroll
+  for (int i = 0; i < 6; ++i) issue_x(0, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xcur[i] += xinc[i];
+  issue_w(0, 0, 0);
+
+  int ci = 0, tap = 0;
+  for (int t = 0; t < nsteps; ++t) {
+    wait_vmcnt<0>();
+    __syncthreads();                                   // step t's data landed for everyone; step t-1's buffers are free
+    {                                                  // stream the next weight slab and a piece of the next patch
+      int ntap = tap + 1, nci = ci;
+      if (ntap == 9) { ntap = 0; ++nci; }
+      if (t + 1 < nsteps) issue_w((t + 1) & 1, ntap, nci << 6);
+      if (tap < 6 && ci + 1 < nch) { issue_x((ci + 1) & 1, tap); xcur[tap] += xinc[tap]; }
+    }
+    const uint4* ldsX = lds + (ci & 1) * XP;
+    const uint4* ldsW = lds + 2 * XP + (t & 1) * WS;
+    const int r = tap / 3, sft = tap - r * 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint4 xf[MI], wf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = (wm * 4 + i + r) * PW + fr + sft;
+        xf[i] = ldsX[row * 8 + ((h * 4 + fg) ^ swz<8>(row))];
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { const int row = wn0 + j * 16 + fr; wf[j] = ldsW[row * 8 + ((h * 4 + fg) ^ swz<8>(row))]; }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+    }
+    if (++tap == 9) { tap = 0; ++ci; }
+  }
+
+  conv_epilogue<T, BM, BN, WM, MI, NJ>(p, acc, n0, lds, [&](int row) {
+    const int ho = h0 + (row >> 4), wo = w0 + (row & 15);
+    return (ho < p.Ho && wo < p.Wo) ? ((long)b * p.Ho + ho) * p.Wo + wo : -1L;
+  });
+}
+
+// ---- 3x3 stride-1 convolution for narrow layers (Cin, Cout <= 64): weights stationary in LDS, persistent blocks ----------
+// With K = 9*Cin <= 576 a tile is nine tiny K steps; in the kernels above each step waits for a DMA issued one step
+// earlier, so a tile costs nine memory latencies for ~1 us of MFMA work (these layers ran at 2-3x their HBM time).
+// Here a block loads ALL nine taps of the weights once (<= 72 KB), then walks its share of the 8x16-pixel output tiles:
+// the 10x18 input patch of tile i+1 streams in (LDS-DMA) while tile i runs its 144 MFMAs per wave straight from LDS and
+// leaves through the staged epilogue.  One wait + three barriers per tile; the layer becomes an HBM stream
+// (patch in, tile out).  One block of four waves per CU (LDS: weights + two patches + epilogue tile).
+struct WsAux { float inv_tiles, inv_tx; int tiles, tx, total; };
+
+template <class T, int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvP p, const WsAux a) {
+  constexpr int BM = 128, WM = 2, WN = 2, MI = 4, NJ = COUT / WN / 16;
+  constexpr int E = 8, CPRW = CIN / E;                 // 16-byte chunks per pixel row: 8 (64 ch) or 4 (32 ch)
+  constexpr int PW = 18, RPP = 256 / CPRW;             // patch width; rows covered by one pass of the 256 threads
+  constexpr int XPASS = (180 + RPP - 1) / RPP, PROWS = XPASS * RPP;
+  constexpr int XP = PROWS * CPRW;                     // uint4 per patch buffer
+  constexpr int WROWS = 9 * COUT, WPASS = (WROWS + RPP - 1) / RPP;
+  constexpr int WL = WPASS * RPP * CPRW;               // uint4 of resident weights
+  constexpr int ET = BM * COUT * 2 / 16;               // uint4 of the epilogue tile
+  constexpr int HS = CPRW / 4;                         // MFMA k-steps (32 channels) per tap
+  static_assert(sizeof(T) == 2 && (CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "narrow 16-bit layers only");
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [WL] weights, [2][XP] patches, [ET] epilogue tile
+  uint4* ldsW = lds;
+  uint4* ldsE = lds + WL + 2 * XP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned lds_base = lds_addr(lds);
+  const int ppos = tid % CPRW, prow = tid / CPRW;
+
+  // ---- resident weights: LDS row R = tap*COUT + n holds w[n][tap*CIN .. +CIN), chunk-swizzled like every other tile
+#pragma unroll
+  for (int i = 0; i < WPASS; ++i) {
+    const int R = prow + RPP * i;
+    const int tap = R / COUT, n = R - tap * COUT;
+    const int chunk = ppos ^ swz<CPRW>(R);
+    const void* src = (R < WROWS && n < p.Cout) ? static_cast<const void*>(reinterpret_cast<const char*>(p.w) +
+                          ((size_t)n * p.Kw + tap * CIN + chunk * E) * sizeof(T)) : static_cast<const void*>(&g_zero16);
+    glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((RPP * i) * CPRW + wave * 64) * 16u));
+  }
+
+  auto issue_patch = [&](int tile, int buf) {          // the 10x18 input patch of output tile `tile`
+    const int b = fdiv(tile, a.tiles, a.inv_tiles), trem = tile - b * a.tiles, ty = fdiv(trem, a.tx, a.inv_tx), tx = trem - ty * a.tx;
+    const int h0 = ty * 8 - 1, w0 = tx * 16 - 1;
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      const int pr = prow + RPP * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const int ih = h0 + py, iw = w0 + px;
+      const bool ok = pr < 180 && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+      const int chunk = ppos ^ swz<CPRW>(pr);
+      const void* src = ok ? static_cast<const void*>(reinterpret_cast<const char*>(p.s0.ptr) +
+                                 ((((long)b * p.s0.H + ih) * p.s0.W + iw) * (long)p.s0.cstride + p.s0.coff + chunk * E) * (long)sizeof(T))
+                           : static_cast<const void*>(&g_zero16);
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(WL + buf * XP + (RPP * i) * CPRW + wave * 64) * 16u));
+    }
+  };
+
+  const int wm = wave & 1, wn0 = (wave >> 1) * (COUT / WN);
+  const int fr = lane & 15, fg = lane >> 4;
+  int tile = blockIdx.x, buf = 0;
+  if (tile < a.total) issue_patch(tile, 0);
+  for (; tile < a.total; tile += gridDim.x, buf ^= 1) {
+    wait_vmcnt<0>();
+    __syncthreads();                                   // weights + this tile's patch landed; the other patch buffer is free
+    if (tile + (int)gridDim.x < a.total) issue_patch(tile + gridDim.x, buf ^ 1);
+    const uint4* ldsX = lds + WL + buf * XP;
+    f32x4 acc[NJ][MI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, sft = tap % 3;
+#pragma unroll
+      for (int h = 0; h < HS; ++h) {
+        uint4 xf[MI], wf[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = (wm * 4 + i + r) * PW + fr + sft;
+          xf[i] = ldsX[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))];
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int nl = wn0 + j * 16 + fg * 4, n = n0 + nl;
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.bias && n < p.Cout) b4 = *reinterpret_cast<const float4*>(p.bias + n);
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            const float v0 = activate<T, ACT>(acc[j][i][0] + b4.x), v1 = activate<T, ACT>(acc[j][i][1] + b4.y);
-            const float v2 = activate<T, ACT>(acc[j][i][2] + b4.z), v3 = activate<T, ACT>(acc[j][i][3] + b4.w);
-            const int row = wm0 + i * 16 + fr;
-            const int ch = (nl >> 3) ^ (rowswz(row) & (CPR - 1));
-            *reinterpret_cast<uint2*>(tilep + row * ROWB + ch * 16 + (nl & 4) * 2) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
-          }
+          const int row = tap * COUT + wn0 + j * 16 + fr;
+          wf[j] = ldsW[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))];
         }
-      };
-      if (p.act == 1) to_lds(std::integral_constant<int, 1>{});
-      else if (p.act == 2) to_lds(std::integral_constant<int, 2>{});
-      else to_lds(std::integral_constant<int, 0>{});
-      __syncthreads();
-      T* outp = reinterpret_cast<T*>(p.out) + p.out_coff + n0;
 #pragma unroll
-      for (int q = 0; q < BM * CPR / NT; ++q) {
-        const int idx = tid + NT * q, row = idx / CPR, ch = idx - row * CPR;
-        const int m = m0 + row;
-        if (m < M && n0 + ch * 8 < p.Cout)
-          *reinterpret_cast<uint4*>(outp + (size_t)m * p.out_cstride + ch * 8) =
-              *reinterpret_cast<const uint4*>(tilep + row * ROWB + (ch ^ (rowswz(row) & (CPR - 1))) * 16);
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int i = 0; i < MI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
       }
-      return;
     }
-  }
-  // direct path: bias -> activation -> (+residual) -> store 4 consecutive channels of one pixel
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int n = n0 + wn0 + j * 16 + fg * 4;
-    if (n >= p.Cout) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm0 + i * 16 + fr;
-      if (m >= M) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = activate_rt<T>(acc[j][i][e] + bv[e], p.act);
-      if (p.res) {
-        float rv[4];
-        const size_t ri = (size_t)m * p.res_cstride + p.res_coff + n;
-        if (p.res_f32) load4<float>(p.res, ri, rv); else load4<T>(p.res, ri, rv);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
-      }
-      const size_t oi = (size_t)m * p.out_cstride + p.out_coff + n;
-      if (p.out_f32) store4<float>(p.out, oi, v); else store4<T>(p.out, oi, v);
-    }
+    const int b = fdiv(tile, a.tiles, a.inv_tiles), trem = tile - b * a.tiles, ty = fdiv(trem, a.tx, a.inv_tx), tx = trem - ty * a.tx;
+    conv_epilogue<T, BM, COUT, WM, MI, NJ>(p, acc, 0, ldsE, [&](int row) {
+      const int ho = ty * 8 + (row >> 4), wo = tx * 16 + (row & 15);
+      return (ho < p.Ho && wo < p.Wo) ? ((long)b * p.Ho + ho) * p.Wo + wo : -1L;
+    });
   }
 }
 
@@ -422,8 +659,93 @@ template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const Conv
   else launch_k<T, 128, 32, 4, SIMPLE, 8, 2>(p, a, (M + 127) / 128, stream);
 }
 
+template <class T, int BN> static void launch_halo(const ConvP& p, hipStream_t stream) {
+  constexpr size_t lds = (size_t)(2 * 184 * 8 + 2 * BN * 8) * 16;
+  static bool configured = false;
+  if (!configured) {
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  HaloAux a{};
+  a.tx = (p.Wo + 15) / 16; a.tiles = ((p.Ho + 7) / 8) * a.tx; a.nt = (p.Cout + BN - 1) / BN;
+  a.inv_tiles = 1.0f / (float)a.tiles; a.inv_tx = 1.0f / (float)a.tx;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN>), dim3(p.B * a.tiles * a.nt), dim3(256), lds, stream, p, a);
+}
+
+// 3x3 s1 p1, one source, whole 64-channel slabs.  Measured per layer (YOLOv9-C, B=64): 6-7 % faster than the generic
+// kernel for 128/256-channel layers whose image is covered by whole 8x16 tiles and whose Cout is a multiple of 128;
+// slower for Cout = 320 (64-wide channel tiles reload the patch five times), for ragged coverage (40x40) and for the
+// 64-channel layers (those are latency-chain bound, see conv3x3_ws_kernel).  Tests force it with variant 3.
+static bool halo_legal(const ConvP& p) {
+  return p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && p.Cin % 64 == 0 && p.Hin == p.Ho && p.Win == p.Wo;
+}
+static bool halo_applicable(const ConvP& p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CLEARCAM_HALO"); on = e ? atoi(e) : 1; }
+  if (!on || !halo_legal(p)) return false;
+  const long covered = (long)((p.Ho + 7) / 8 * 8) * ((p.Wo + 15) / 16 * 16);
+  return p.Cin >= 128 && p.Cout % 128 == 0 && (long)p.Ho * p.Wo == covered;
+}
+
+template <class T, int CIN, int COUT> static void launch_ws(const ConvP& p, hipStream_t stream) {
+  constexpr int CPRW = CIN / 8, RPP = 256 / CPRW;
+  constexpr int XP = (180 + RPP - 1) / RPP * RPP * CPRW, WL = (9 * COUT + RPP - 1) / RPP * RPP * CPRW;
+  constexpr size_t lds = (size_t)(WL + 2 * XP + 128 * COUT * 2 / 16) * 16;
+  static int cus = 0;
+  if (!cus) {
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<T, CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dev = 0; hipDeviceProp_t pr;
+    CC_HIP(hipGetDevice(&dev)); CC_HIP(hipGetDeviceProperties(&pr, dev));
+    cus = pr.multiProcessorCount;
+  }
+  WsAux a{};
+  a.tx = (p.Wo + 15) / 16; a.tiles = ((p.Ho + 7) / 8) * a.tx; a.total = p.B * a.tiles;
+  a.inv_tiles = 1.0f / (float)a.tiles; a.inv_tx = 1.0f / (float)a.tx;
+  const int blocks_per_cu = (int)(160 * 1024 / lds);           // persistent: as many blocks as fit, each walks total/grid tiles
+  hipLaunchKernelGGL((conv3x3_ws_kernel<T, CIN, COUT>), dim3(std::min(a.total, cus * std::max(1, blocks_per_cu))), dim3(256), lds, stream, p, a);
+}
+
+// narrow 3x3 s1 p1 layers: Cin in {32, 64}, Cout <= 64 (a multiple of 8), one source
+static bool ws_legal(const ConvP& p) {
+  return p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && (p.Cin == 32 || p.Cin == 64) &&
+         p.Cout <= 64 && p.Cout % 8 == 0 && p.Hin == p.Ho && p.Win == p.Wo;
+}
+static bool ws_applicable(const ConvP& p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CLEARCAM_WS"); on = e ? atoi(e) : 1; }
+  if (!on || !ws_legal(p)) return false;
+  const long covered = (long)((p.Ho + 7) / 8 * 8) * ((p.Wo + 15) / 16 * 16);
+  if ((long)p.Ho * p.Wo * 5 < covered * 4) return false; // 8x16 tiles must not waste more than a fifth of their pixels
+  // Measured (YOLOv9-C, B=64): 32-channel layers (52 KB of LDS, three blocks and three patches in flight per CU) run 27 %
+  // faster than the generic kernel.  With 64 input channels the 74 KB of weights leave room for one block per CU - one
+  // patch in flight, ~3.7 us per tile plus ~40 us to fill 256 weight copies - which only pays off once a block walks
+  // many tiles: -7 % at 160x160 (50 tiles per block), +20 % at 80x80 (12 tiles per block).
+  if (p.Cin == 32 && p.Cout <= 32) return true;
+  const long tiles = (long)p.B * (covered / 128);
+  return tiles >= 256L * 32;
+}
+template <class T> static void launch_ws_t(const ConvP& p, hipStream_t stream) {
+  if (p.Cin == 64) { if (p.Cout > 32) launch_ws<T, 64, 64>(p, stream); else launch_ws<T, 64, 32>(p, stream); }
+  else { if (p.Cout > 32) launch_ws<T, 32, 64>(p, stream); else launch_ws<T, 32, 32>(p, stream); }
+}
+
 template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   const int M = p.B * p.Ho * p.Wo;
+  if constexpr (sizeof(T) == 2) {
+    if (p.variant == 4 || (p.variant == 0 && ws_applicable(p))) {
+      CC_CHECK(ws_legal(p), "weights-stationary 3x3: shape not eligible");
+      launch_ws_t<T>(p, stream);
+      CC_HIP(hipGetLastError());
+      return;
+    }
+    if (p.variant == 3 || (p.variant == 0 && halo_applicable(p))) {
+      CC_CHECK(halo_legal(p), "halo-resident 3x3: shape not eligible");
+      auto padded = [&](int bn) { return (p.Cout + bn - 1) / bn * bn; };
+      if (padded(64) < padded(128)) launch_halo<T, 64>(p, stream); else launch_halo<T, 128>(p, stream);
+      CC_HIP(hipGetLastError());
+      return;
+    }
+  }
   auto padded = [&](int bn) { return (p.Cout + bn - 1) / bn * bn; };
   int bn = 128;
   if (padded(64) < padded(bn)) bn = 64;

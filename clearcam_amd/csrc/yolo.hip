@@ -744,7 +744,8 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
   c.B = B; c.Hin = H; c.Win = W; c.Cin = Cin; c.ks = k; c.stride = stride; c.pad = k / 2;
   c.Ho = (H + 2 * c.pad - k) / stride + 1; c.Wo = (W + 2 * c.pad - k) / stride + 1; c.Cout = Cout; c.Ktot = k * k * Cin; c.Kw = pc.kw;
   c.w = pc.w; c.bias = pc.bias; c.out = out_dev; c.out_cstride = Cout; c.out_coff = 0; c.out_f32 = 0; c.res = nullptr; c.act = act;
-  if (force_direct) launch_conv_direct(dtype, c, (hipStream_t)stream); else launch_conv(dtype, c, (hipStream_t)stream);
+  c.variant = force_direct;                              // 0 auto, 1 direct, 2 generic MFMA, 3 halo-resident, 4 weights-stationary
+  if (force_direct == 1) launch_conv_direct(dtype, c, (hipStream_t)stream); else launch_conv(dtype, c, (hipStream_t)stream);
   CC_HIP(hipStreamSynchronize((hipStream_t)stream));
   hipFree(pc.w); hipFree(pc.bias);
   CC_API_END

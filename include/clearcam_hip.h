@@ -62,7 +62,9 @@ void cc_yolo_destroy(cc_yolo* h);
 
 /* Single-layer entry used by the parity tests: NHWC conv + bias + optional SiLU on device buffers.
  * x (B,H,W,Cin) and out (B,Ho,Wo,Cout) in storage dtype `dtype`; w OIHW float32 host, bias host.
- * groups>1 is densified to block-diagonal weights exactly as the detector does for the head convs. */
+ * groups>1 is densified to block-diagonal weights exactly as the detector does for the head convs.
+ * force_direct selects the kernel: 0 = what the detector would pick, 1 = direct (non-MFMA) fallback, 2 = generic MFMA
+ * implicit GEMM, 3 = halo-resident 3x3, 4 = weights-stationary 3x3 (3 and 4 fail if the shape is not eligible). */
 int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, const float* w_oihw,
                    const float* bias, int Cout, int k, int stride, int groups, int act, void* out_dev,
                    int force_direct, void* stream);

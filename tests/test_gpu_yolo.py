@@ -60,6 +60,20 @@ CONV_CASES = [
     ("3x3_32_32", 1, 32, 48, 48, 32, 3, 1, 1),
     ("ragged_m", 1, 64, 13, 7, 64, 3, 1, 1),              # M = 91: not a multiple of the 128-pixel tile
 ]
+# (name, B, Cin, H, W, Cout, variant): the specialised 3x3 kernels, forced through cc_conv2d_nhwc's selector (16-bit modes)
+SPECIAL_CASES = [
+    ("halo_ragged", 2, 64, 14, 30, 64, 3),               # ragged 8x16 tiles
+    ("halo_3slabs", 3, 192, 24, 32, 128, 3),             # several 64-channel slabs
+    ("halo_cout320", 1, 128, 16, 16, 320, 3),            # 64-wide channel tiles, five of them
+    ("halo_1row", 1, 64, 8, 160, 192, 3),
+    ("ws_64_64", 5, 64, 24, 48, 64, 4),                  # more tiles than one block's share: the persistent loop
+    ("ws_64_64_ragged", 2, 64, 13, 21, 64, 4),
+    ("ws_32_32", 3, 32, 16, 32, 32, 4),
+    ("ws_32_64", 1, 32, 20, 30, 64, 4),
+    ("ws_64_32", 2, 64, 9, 17, 32, 4),
+    ("ws_64_48", 1, 64, 16, 16, 48, 4),                  # Cout not a tile multiple
+    ("generic_forced", 1, 64, 16, 16, 64, 2),
+]
 TOL = {"f32": 2e-5, "f16": 3e-3, "bf16": 2e-2}            # max |err| / max |ref|
 
 
@@ -78,6 +92,32 @@ def test_conv_layer_matches_torch(case, dtype):
     assert got.shape == ref.shape
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err <= TOL[dtype], err
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", SPECIAL_CASES, ids=[c[0] for c in SPECIAL_CASES])
+def test_specialised_3x3_kernels_match_torch(case, dtype):
+    _, B, Cin, H, W_, Cout, variant = case
+    g = torch.Generator().manual_seed(hash(case[0]) % 1000)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b, padding=1))
+    got = conv_hip(x, w, b, 1, 1, 1, dtype, force_direct=variant)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= TOL[dtype], err
+    generic = conv_hip(x, w, b, 1, 1, 1, dtype, force_direct=2)      # same products, same f32 accumulation order per k-slab? no: only close
+    assert float((got - generic).abs().max() / ref.abs().max()) <= TOL[dtype]
+
+
+def test_specialised_kernels_refuse_ineligible_shapes():
+    from clearcam_amd._lib import CCError
+    x, w, b = torch.randn(1, 128, 16, 16), torch.randn(64, 128, 3, 3), torch.zeros(64)
+    with pytest.raises(CCError):
+        conv_hip(x, w, b, 1, 1, 1, "bf16", force_direct=4)           # Cin = 128: not a narrow layer
+    x, w = torch.randn(1, 32, 16, 16), torch.randn(64, 32, 3, 3)
+    with pytest.raises(CCError):
+        conv_hip(x, w, b, 1, 1, 1, "bf16", force_direct=3)           # Cin = 32: not whole 64-channel slabs
 
 
 def test_conv_direct_fallback_odd_channels():
