@@ -85,6 +85,10 @@ __device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_byte_a
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(src), "s"(lds_wave_byte_addr) : "memory");
 }
+// Same, for kernels that use M0 for nothing else: declared clobbered instead of saved/restored (2 SALU less per DMA).
+__device__ __forceinline__ void glds16_m0(const void* src, unsigned lds_wave_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_wave_byte_addr) : "memory", "m0");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
@@ -103,13 +107,67 @@ template <int CPRW> __device__ __forceinline__ int swz(int row) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// bias + activation (compile-time) + pack, fragment -> chunk-swizzled LDS tile (row = pixel, BN channels per row)
+template <class T, int ACT, int BN, int MI, int NJ>
+__device__ __forceinline__ void stage_tile(const ConvP& p, const f32x4 (&acc)[NJ][MI], char* tilep, int n0, int wm0, int wn0, int fr, int fg) {
+  constexpr int ROWB = BN * 2, CPR = BN / 8;
+  auto rowswz = [](int row) { if constexpr (CPR <= 16) return row / (16 / CPR); else return row * (CPR / 16); };
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int nl = wn0 + j * 16 + fg * 4, n = n0 + nl;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n < p.Cout) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const f32x4 av = acc[j][i];
+      const float v0 = activate<T, ACT>(av[0] + b4.x), v1 = activate<T, ACT>(av[1] + b4.y);
+      const float v2 = activate<T, ACT>(av[2] + b4.z), v3 = activate<T, ACT>(av[3] + b4.w);
+      const int row = wm0 + i * 16 + fr;
+      const int ch = (nl >> 3) ^ (rowswz(row) & (CPR - 1));
+      *reinterpret_cast<uint2*>(tilep + row * ROWB + ch * 16 + (nl & 4) * 2) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
+    }
+  }
+}
+
+// bias + activation (compile-time: a runtime switch per value keeps the 64-fragment accumulator of the 256x256 kernel
+// from being promoted to registers) + optional residual, 4 consecutive channels of one pixel stored from registers
+template <class T, int ACT, int MI, int NJ>
+__device__ __forceinline__ void direct_tile(const ConvP& p, const f32x4 (&acc)[NJ][MI], const long (&mrow)[MI], int nbase) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = nbase + j * 16;
+    const bool nok = n < p.Cout;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && nok) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const f32x4 av = acc[j][i];
+      const long m = mrow[i];
+      if (nok && m >= 0) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = activate<T, ACT>(av[e] + bv[e]);
+        if (p.res) {
+          float rv[4];
+          const size_t ri = (size_t)m * p.res_cstride + p.res_coff + n;
+          if (p.res_f32) load4<float>(p.res, ri, rv); else load4<T>(p.res, ri, rv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
+        }
+        const size_t oi = (size_t)m * p.out_cstride + p.out_coff + n;
+        if (p.out_f32) store4<float>(p.out, oi, v); else store4<T>(p.out, oi, v);
+      }
+    }
+  }
+}
+
 // Epilogue shared by the conv kernels.  acc[j][i] = 4 consecutive output channels (n0 + wn0 + 16j + 4*(lane>>4) + e) of
 // tile pixel row = wm0 + 16i + (lane&15);  pix(row) -> flat output pixel index (b*Ho + ho)*Wo + wo, or -1 outside the image.
 // 16-bit outputs without residual go through LDS (chunk-swizzled, the K stages are dead by now) so that every pixel's BN
 // channels leave as 16-byte-per-lane, line-contiguous stores; f32 outputs / residual adds store from registers.
-template <class T, int BM, int BN, int WM, int MI, int NJ, class PixFn>
+template <class T, int BM, int BN, int WM, int MI, int NJ, int NT = 2 * BM, class PixFn>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][MI], int n0, uint4* lds, PixFn pix) {
-  constexpr int NT = 2 * BM, WN = NT / 64 / WM;
+  constexpr int WN = NT / 64 / WM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave % WM) * (BM / WM), wn0 = (wave / WM) * (BN / WN);
   const int fr = lane & 15, fg = lane >> 4;
@@ -120,26 +178,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][M
     if (!p.res && !p.out_f32 && (p.Cout % 8 == 0) && (p.out_coff % 8 == 0) && (p.out_cstride % 8 == 0)) {
       __syncthreads();                                 // every wave is done reading the K stages
       char* tilep = reinterpret_cast<char*>(lds);
-      auto to_lds = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int nl = wn0 + j * 16 + fg * 4, n = n0 + nl;
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.bias && n < p.Cout) b4 = *reinterpret_cast<const float4*>(p.bias + n);
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            const float v0 = activate<T, ACT>(acc[j][i][0] + b4.x), v1 = activate<T, ACT>(acc[j][i][1] + b4.y);
-            const float v2 = activate<T, ACT>(acc[j][i][2] + b4.z), v3 = activate<T, ACT>(acc[j][i][3] + b4.w);
-            const int row = wm0 + i * 16 + fr;
-            const int ch = (nl >> 3) ^ (rowswz(row) & (CPR - 1));
-            *reinterpret_cast<uint2*>(tilep + row * ROWB + ch * 16 + (nl & 4) * 2) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
-          }
-        }
-      };
-      if (p.act == 1) to_lds(std::integral_constant<int, 1>{});
-      else if (p.act == 2) to_lds(std::integral_constant<int, 2>{});
-      else to_lds(std::integral_constant<int, 0>{});
+      if (p.act == 1) stage_tile<T, 1, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
+      else if (p.act == 2) stage_tile<T, 2, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
+      else stage_tile<T, 0, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
       __syncthreads();
       T* outp = reinterpret_cast<T*>(p.out) + p.out_coff + n0;
 #pragma unroll
@@ -154,30 +195,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][M
     }
   }
   // direct path: bias -> activation -> (+residual) -> store 4 consecutive channels of one pixel
+  long mrow[MI];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int n = n0 + wn0 + j * 16 + fg * 4;
-    if (n >= p.Cout) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const long m = pix(wm0 + i * 16 + fr);
-      if (m < 0) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = activate_rt<T>(acc[j][i][e] + bv[e], p.act);
-      if (p.res) {
-        float rv[4];
-        const size_t ri = (size_t)m * p.res_cstride + p.res_coff + n;
-        if (p.res_f32) load4<float>(p.res, ri, rv); else load4<T>(p.res, ri, rv);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
-      }
-      const size_t oi = (size_t)m * p.out_cstride + p.out_coff + n;
-      if (p.out_f32) store4<float>(p.out, oi, v); else store4<T>(p.out, oi, v);
-    }
-  }
+  for (int i = 0; i < MI; ++i) mrow[i] = pix(wm0 + i * 16 + fr);
+  if (p.act == 1) direct_tile<T, 1, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
+  else if (p.act == 2) direct_tile<T, 2, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
+  else direct_tile<T, 0, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
 }
 
 // SIMPLE: one source, no upsample, ks <= 3 -> incremental row pointers.  !SIMPLE: general two-source / upsample path.
@@ -370,6 +393,180 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
 
   // ---- epilogue ------------------------------------------------------------------------------------
   conv_epilogue<T, BM, BN, WM, MI, NJ>(p, acc, n0, lds, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; });
+}
+
+// ---- 256 x 256 tile, four waves of 128 x 128: the schedule for wide, deep GEMM-shaped layers ---------------------------------
+// Why a second main loop: in the 128x128 kernel every MFMA costs half a ds_read_b128 and every K step two barriers' worth of
+// skew; the ablation puts its ceiling near 0.9 PF while the library reaches 1.0-1.2 PF with 256x256 macro tiles.
+// Here one block per CU, one wave per SIMD; a wave owns 128 pixels x 128 channels (64 accumulator fragments = 256 registers,
+// AGPRs), so a 32-wide k-substep is 64 MFMAs fed by 16 fragment reads (0.25 per MFMA).  Fragments are double-buffered in
+// registers and the loop has ONE barrier per K step, placed in the middle of the second substep:
+//     64 MFMA on F0(t)         | 16 ds_read -> F1(t)
+//     32 MFMA on F1(t)
+//     s_waitcnt vmcnt(0) ; barrier          stage t+1 has landed for everyone, nobody reads stage t any more
+//     32 MFMA on F1(t)         | 16 DMA issues for stage t+2 (into the buffer of stage t) | 16 ds_read -> F0(t+1)
+// so the LDS-DMA of a stage is issued a whole step before it is needed and the matrix pipe never waits for a fragment.
+// sched_barrier pins the interleave (the scheduler otherwise hoists all reads to the top and spills).
+template <class T>
+__global__ __launch_bounds__(256) void conv_big_kernel(const ConvP p, const ConvAux a) {
+  constexpr int BM = 256, BN = 256, NT = 256, WM = 2, WN = 2, MI = 8, NJ = 8;
+  constexpr int E = 8, CPRW = 8, BK = 64, RPP = NT / CPRW, XR = BM / RPP, WR = BN / RPP;
+  constexpr int STAGE = (BM + BN) * CPRW;              // uint4 per stage (64 KB); two stages = the 128 KB epilogue tile
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
+  const unsigned lds_base = lds_addr(lds);
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt_ = wg / a.nt;
+  const int m0 = mt_ * BM, n0 = (wg - mt_ * a.nt) * BN;
+
+  // ---- loader state (same scheme as conv_mfma_kernel's SIMPLE path) ------------------------------------------------------
+  const int ppos = tid % CPRW, prow = tid / CPRW;
+  const int chunk = ppos ^ swz<CPRW>(prow);
+  const char* rowp[XR]; unsigned vmask[XR];
+  const char* cur[XR]; unsigned inc[XR];
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    const int m = m0 + prow + RPP * i;
+    if (a.is1x1) {
+      rowp[i] = reinterpret_cast<const char*>(p.s0.ptr) + ((size_t)m * p.s0.cstride + p.s0.coff) * sizeof(T);
+      vmask[i] = m < M ? 1u : 0u;
+    } else {
+      const int mm = m < M ? m : 0;
+      const int b = fdiv(mm, hw, a.inv_hw), rem = mm - b * hw, ho = fdiv(rem, p.Wo, a.inv_wo), wo = rem - ho * p.Wo;
+      const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+      unsigned hm = 0, wmk = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        hm |= (unsigned)(r < p.ks && (unsigned)(h0 + r) < (unsigned)p.Hin) << r;
+        wmk |= (unsigned)(r < p.ks && (unsigned)(w0 + r) < (unsigned)p.Win) << r;
+      }
+      const unsigned vm = ((hm & 1u) ? wmk : 0u) | ((hm & 2u) ? wmk << p.ks : 0u) | ((hm & 4u) ? wmk << (2 * p.ks) : 0u);
+      vmask[i] = m < M ? vm : 0u;
+      rowp[i] = reinterpret_cast<const char*>(p.s0.ptr) +
+                ((((long)b * p.s0.H + h0) * p.s0.W + w0) * (long)p.s0.cstride + p.s0.coff) * (long)sizeof(T);
+    }
+  }
+  const char* wcur[WR]; unsigned winc[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int n = n0 + prow + RPP * i;
+    const bool ok = n < p.Cout;
+    wcur[i] = ok ? reinterpret_cast<const char*>(p.w) + ((size_t)n * p.Kw + chunk * E) * sizeof(T) : reinterpret_cast<const char*>(&g_zero16);
+    winc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
+  }
+  int k0 = chunk * E, kc, kr, ks_;
+  if (k0 < p.Cin) { kc = k0; kr = 0; ks_ = 0; }
+  else { const int tap = k0 / p.Cin; kc = k0 - tap * p.Cin; kr = tap / p.ks; ks_ = tap - kr * p.ks; }
+  auto retarget = [&]() {
+    const bool kok = kr < p.ks;
+    const int tbit = kr * p.ks + ks_;
+    const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc) * (long)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const bool ok = kok && ((vmask[i] >> tbit) & 1u);
+      cur[i] = ok ? rowp[i] + delta : reinterpret_cast<const char*>(&g_zero16);
+      inc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
+    }
+  };
+  retarget();
+  auto advance_k = [&]() {
+    k0 += BK; kc += BK;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) wcur[i] += winc[i];
+    if (kc >= p.Cin) {
+      do { kc -= p.Cin; if (++ks_ == p.ks) { ks_ = 0; ++kr; } } while (kc >= p.Cin);
+      retarget();
+    } else {
+#pragma unroll
+      for (int i = 0; i < XR; ++i) cur[i] += inc[i];
+    }
+  };
+  // DMA piece q of a stage: q < XR -> pixel rows prow + 32q, else weight rows prow + 32(q - XR)
+  auto issue_piece = [&](int stage, int q) {
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(stage * STAGE + wave * 64) * 16u);
+    if (q < XR) glds16_m0(cur[q], sbase + q * (NT * 16u));
+    else glds16_m0(wcur[q - XR], sbase + (BM * CPRW + (q - XR) * NT) * 16u);
+  };
+
+  const int wm0 = (wave % WM) * (BM / WM), wn0 = (wave / WM) * (BN / WN);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nkt = (p.Ktot + BK - 1) / BK;
+  f32x4 acc[NJ][MI];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment index q < 8 -> pixel fragment q, else weight fragment q - 8, of k-substep h in `stage`
+  uint4 f0[16], f1[16];
+  auto frag = [&](int stage, int h, int q) -> uint4 {
+    const int row = (q < MI ? wm0 + q * 16 : BM + wn0 + (q - MI) * 16) + fr;   // row in the stage: pixels first, then weights
+    const int srow = q < MI ? row : row - BM;                                    // swizzle uses the row inside its own slab
+    return lds[stage * STAGE + row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(srow))];
+  };
+
+  // prologue: stages 0 and 1 in flight, stage 0 landed, F0(0) in registers
+#pragma unroll
+  for (int q = 0; q < XR + WR; ++q) issue_piece(0, q);
+  if (nkt > 1) {
+    advance_k();
+#pragma unroll
+    for (int q = 0; q < XR + WR; ++q) issue_piece(1, q);
+    wait_vmcnt<XR + WR>();                               // only loads in flight here: they complete in order
+  } else {
+    wait_vmcnt<0>();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) f0[q] = frag(0, 0, q);
+
+  // one K step; MORE = a next step exists (barrier + its first fragments), MORE2 = a step after that exists (its DMA).
+  // The last two steps are peeled so that the steady-state body has no branches between MFMA groups.
+  auto step = [&](int kt, auto more_tag, auto more2_tag) {
+    constexpr bool MORE = decltype(more_tag)::value, MORE2 = decltype(more2_tag)::value;
+    const int st = kt & 1;
+    // substep 0: 64 MFMAs on F0, the 16 reads of F1 spread underneath
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      f1[g] = frag(st, 1, g);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = g >> 1, i = (g & 1) * 4 + u; Mma<T>::run(f0[MI + j], f0[i], acc[j][i]); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // substep 1, first half
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = g >> 1, i = (g & 1) * 4 + u; Mma<T>::run(f1[MI + j], f1[i], acc[j][i]); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (MORE) {
+      wait_vmcnt<0>();
+      __syncthreads();                                   // stage kt+1 landed for everyone; stage kt is dead
+      if constexpr (MORE2) advance_k();
+    }
+    // substep 1, second half: DMA of stage kt+2 into the dead buffer and the reads of F0(kt+1) ride under the MFMAs
+#pragma unroll
+    for (int g = 8; g < 16; ++g) {
+      if constexpr (MORE2) { issue_piece(st, 2 * (g - 8)); issue_piece(st, 2 * (g - 8) + 1); }
+      if constexpr (MORE) { f0[2 * (g - 8)] = frag(st ^ 1, 0, 2 * (g - 8)); f0[2 * (g - 8) + 1] = frag(st ^ 1, 0, 2 * (g - 8) + 1); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = g >> 1, i = (g & 1) * 4 + u; Mma<T>::run(f1[MI + j], f1[i], acc[j][i]); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int kt = 0;
+  for (; kt + 2 < nkt; ++kt) step(kt, std::true_type{}, std::true_type{});
+  if (kt + 1 < nkt) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
+  step(kt, std::false_type{}, std::false_type{});
+  conv_epilogue<T, BM, BN, WM, MI, NJ, NT>(p, acc, n0, lds, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; });
 }
 
 // ---- 3x3 stride-1 convolution with the input halo tile resident in LDS ---------------------------------------------------
@@ -653,7 +850,23 @@ template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const Conv
     g_cfg[0] = 128; g_cfg[1] = 2; g_cfg[2] = 128; g_cfg[3] = 2;
     if (const char* e = getenv("CLEARCAM_CONV_CFG")) sscanf(e, "%d,%d,%d,%d", &g_cfg[0], &g_cfg[1], &g_cfg[2], &g_cfg[3]);
   }
-  if (bn == 256) launch_k<T, 256, 256, 4, SIMPLE, 8, 2>(p, a, (M + 255) / 256, stream);
+  if (bn == 256) {
+    if constexpr (SIMPLE && sizeof(T) == 2) {
+      static int sched = -1;
+      if (sched < 0) { const char* e = getenv("CLEARCAM_BIG_SCHED"); sched = e ? atoi(e) : 1; }
+      if (sched) {
+        constexpr size_t lds = (size_t)2 * 512 * 8 * 16;
+        static bool configured = false;
+        if (!configured) {
+          CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          configured = true;
+        }
+        hipLaunchKernelGGL((conv_big_kernel<T>), dim3(((M + 255) / 256) * a.nt), dim3(256), lds, stream, p, a);
+        return;
+      }
+    }
+    launch_k<T, 256, 256, 4, SIMPLE, 8, 2>(p, a, (M + 255) / 256, stream);
+  }
   else if (bn == 128) launch_cfg<T, 128, SIMPLE>(p, a, M, g_cfg[0], g_cfg[1], stream);
   else if (bn == 64) launch_cfg<T, 64, SIMPLE>(p, a, M, g_cfg[2], g_cfg[3], stream);
   else launch_k<T, 128, 32, 4, SIMPLE, 8, 2>(p, a, (M + 127) / 128, stream);
@@ -750,11 +963,17 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   int bn = 128;
   if (padded(64) < padded(bn)) bn = 64;
   if (padded(32) < padded(bn)) bn = 32;
-  {   // 256x256 tiles (3.9 B of L1 traffic per kFLOP instead of 7.8) for wide, deep GEMMs: opt-in with CLEARCAM_BIG_TILE=1
-      // (measured equal to 128x128 within 3 %: the single 8-wave block per CU loses what the halved L1 traffic gains)
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("CLEARCAM_BIG_TILE"); big = e ? atoi(e) : 0; }
-    if (big && sizeof(T) == 2 && p.Cout % 256 == 0 && p.Ktot >= big * 512 && M >= 256 * 256) bn = 256;
+  {   // 256x256 tiles / four-wave single-barrier schedule (conv_big_kernel) for wide, deep, GEMM-shaped layers.
+      // One block per CU, so whole rounds of 256 tiles matter: taken when K >= 1024 and the last round wastes <= 12 %
+      // (measured: -7..-18 % on such layers, +3..+16 % when K = 512 or when 400-800 tiles leave a half-empty round).
+      // CLEARCAM_BIG_TILE=0 disables, -1 forces it for every Cout % 256 == 0 layer (tests use variant 5).
+    static int big = -2;
+    if (big == -2) { const char* e = getenv("CLEARCAM_BIG_TILE"); big = e ? atoi(e) : 1; }
+    if (sizeof(T) == 2 && p.Cout % 256 == 0) {
+      const long tiles = (long)((M + 255) / 256) * (p.Cout / 256), rounds = (tiles + 255) / 256;
+      const bool fits = p.Ktot >= 1024 && tiles >= 256 && rounds * 256 * 100 <= tiles * 112;
+      if ((big > 0 && fits && p.variant == 0) || big < 0 || p.variant == 5) bn = 256;
+    }
   }
   ConvAux a{};
   a.nt = (p.Cout + bn - 1) / bn;

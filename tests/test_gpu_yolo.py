@@ -287,3 +287,26 @@ def test_small_model_sizes_run(sd_t):
         got = _yolo(size, 640, sd, "f32").detect_batch(frames)
         n_ref, n_got, n_match, box_err, sc_err = yo.match_detections(ref[0], got[0], 0.9)
         assert n_match >= 0.99 * max(n_ref, n_got) - 1 and box_err <= 0.64 and sc_err <= 1e-3, (size, n_ref, n_got, n_match)
+
+
+BIG_CASES = [
+    ("big_1x1", 1, 512, 48, 48, 256, 1),                 # 9 m-tiles of 256 pixels, ragged last tile, 8 K steps
+    ("big_1x1_k64", 2, 64, 16, 16, 512, 1),              # a single K step: prologue-only pipeline
+    ("big_1x1_k128", 1, 128, 32, 40, 256, 1),            # two K steps
+    ("big_3x3", 1, 128, 24, 24, 256, 3),                 # im2col loader with halo taps, 18 K steps
+    ("big_3x3_odd", 1, 192, 17, 19, 512, 3),             # K = 1728 = 27 steps (odd), ragged pixels, two channel tiles
+]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", BIG_CASES, ids=[c[0] for c in BIG_CASES])
+def test_big_tile_kernel_matches_torch(case, dtype):
+    """256x256-tile, four-wave, single-barrier kernel (variant 5) against torch, with and without activation/bias."""
+    _, B, Cin, H, W_, Cout, k = case
+    g = torch.Generator().manual_seed(hash(case[0]) % 1000)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b, padding=k // 2))
+    got = conv_hip(x, w, b, 1, 1, 1, dtype, force_direct=5)
+    assert float((got - ref).abs().max() / ref.abs().max()) <= TOL[dtype]

@@ -4,7 +4,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 last = None
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    if "conv_mfma" in n or "Cijk" in n:
+    if "conv_" in n or "Cijk" in n:
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         key = (n[:60], r.get("Grid_Size_X", r.get("Grid_Size", "")))
         if key != last: print()
