@@ -67,7 +67,7 @@ def clip_side_metrics(device_index: int, dev) -> dict:
     from clearcam_amd.weights import synthetic_clip_state_dict
     out = {}
     m = OpenCLIP(state_dict=synthetic_clip_state_dict(CLIP_L14, 4321), arch=CLIP_L14, dtype="bf16", device=device_index)
-    B = 256
+    B = 255                                      # 255 images x 257 tokens = 65535 rows: whole rounds of 256-row GEMM tiles on 256 CUs
     x = torch.rand(B, 3, 224, 224, device=dev) * 2 - 1
     emb = torch.empty(B, 768, device=dev)
     for _ in range(2):

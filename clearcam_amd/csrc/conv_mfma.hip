@@ -47,11 +47,17 @@ struct ConvAux {
 template <class T, int ACT> __device__ __forceinline__ float activate(float x) {
   if constexpr (ACT == 1) {            // SiLU
     if constexpr (sizeof(T) == 4) return x / (1.0f + expf(-x));
-    else return x * __frcp_rn(1.0f + __expf(-x));
+    else return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));   // v_exp_f32 + v_rcp_f32 (1 ulp): plenty for a 16-bit result
   } else if constexpr (ACT == 2) {     // tinygrad Tensor.gelu(): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))  
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     if constexpr (sizeof(T) == 4) return 0.5f * x * (1.0f + tanhf(u));
-    else { const float e = __expf(2.0f * u); return 0.5f * x * (1.0f + (1.0f - 2.0f * __frcp_rn(e + 1.0f))); }
+    else {
+      // 0.5 x (1 + tanh u) = x * sigmoid(2u) = x / (1 + 2^(-2u log2 e)): one fma chain, one v_exp_f32, one v_rcp_f32.
+      // The epilogue is not overlapped with MFMA work in the one-block-per-CU kernels, so its VALU count is paid in full.
+      const float t = x * x;
+      const float z = x * __builtin_fmaf(t, -0.044715f * 2.0f * 0.7978845608028654f * 1.4426950408889634f, -2.0f * 0.7978845608028654f * 1.4426950408889634f);
+      return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+    }
   } else return x;
 }
 template <class T> __device__ __forceinline__ float activate_rt(float x, int act) {
@@ -972,7 +978,8 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
     if (sizeof(T) == 2 && p.Cout % 256 == 0) {
       const long tiles = (long)((M + 255) / 256) * (p.Cout / 256), rounds = (tiles + 255) / 256;
       const bool fits = p.Ktot >= 1024 && tiles >= 256 && rounds * 256 * 100 <= tiles * 112;
-      if ((big > 0 && fits && p.variant == 0) || big < 0 || p.variant == 5) bn = 256;
+      // layers with a residual keep the 128x128 kernel: their f32 read-modify-write epilogue needs another block to hide behind
+      if ((big > 0 && fits && !p.res && p.variant == 0) || big < 0 || p.variant == 5) bn = 256;
     }
   }
   ConvAux a{};
