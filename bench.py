@@ -205,6 +205,9 @@ def main() -> None:
         conv_s = prof["conv_ms"] * 1e-3
         achieved = alg_flops / conv_s / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        # PMC-measured HBM traffic of the conv kernels for the headline configuration only (counters cannot be read in-process)
+        default_cfg = (args.size, args.res, B, args.dtype, fh, fw) == ("c", 640, 64, "bf16", 640, 640)
+        traffic = 26.37e9 if default_cfg else None
         line = {
             "metric": f"yolov9{args.size}_{args.res}x{args.res}_frames_per_sec" if (fh, fw) == (args.res, args.res)
                       else f"yolov9{args.size}_{fh}x{fw}_letterbox{args.res}_frames_per_sec",
@@ -217,8 +220,11 @@ def main() -> None:
                        "batch_per_gpu": B, "parallelism": f"one camera batch per GPU x{world}, no collective",
                        "detections_last_batch": n_det},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
-                         "kernel": "conv_mfma_kernel (all instantiations)",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per step of the conv kernels from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                         "(profiles/r01c_yolo_bf16_b64.txt, FETCH x2 per the gfx950 correction); not re-measured in this run"
+                                         if traffic else None,
+                         "kernel": "conv kernels: conv_mfma_kernel (all instantiations) + conv_big_kernel + conv3x3_halo_kernel + conv3x3_ws_kernel",
                          "alg_gflop_per_step": round(alg_flops / 1e9, 2), "kernel_ms_per_step": round(prof["conv_ms"], 3),
                          "launches_per_step": prof["conv_launches"],
                          "other_ms_per_step": {k: round(prof[k], 3) for k in ("pool_ms", "decode_ms", "nms_ms")}},

@@ -938,7 +938,9 @@ static bool ws_applicable(const ConvP& p) {
   // Measured (YOLOv9-C, B=64): 32-channel layers (52 KB of LDS, three blocks and three patches in flight per CU) run 27 %
   // faster than the generic kernel.  With 64 input channels the 74 KB of weights leave room for one block per CU - one
   // patch in flight, ~3.7 us per tile plus ~40 us to fill 256 weight copies - which only pays off once a block walks
-  // many tiles: -7 % at 160x160 (50 tiles per block), +20 % at 80x80 (12 tiles per block).
+  // many tiles: -7 % at 160x160 (50 tiles per block), +20 % at 80x80 (12 tiles per block).  (Holding the weights in
+  // registers instead - 144 VGPRs per wave, two blocks per CU - was tried and was slower still: the register pressure
+  // pushes address temporaries to scratch, and every scratch reload waits on vmcnt, i.e. on the patch prefetch.)
   if (p.Cin == 32 && p.Cout <= 32) return true;
   const long tiles = (long)p.B * (covered / 128);
   return tiles >= 256L * 32;
