@@ -92,6 +92,24 @@ def clip_side_metrics(device_index: int, dev) -> dict:
     m.encode_tokens(toks)
     out["text_embeds_per_sec"] = round(64 / (time.perf_counter() - t0), 1)
     m.close()
+    # ViT-B/32, the model the north star names (the reference code itself runs ViT-L/14): same engine, 50 tokens per image
+    from clearcam_amd.arch import CLIP_B32
+    mb = OpenCLIP(state_dict=synthetic_clip_state_dict(CLIP_B32, 99), arch=CLIP_B32, dtype="bf16", device=device_index)
+    Bb = 1024
+    xb = torch.rand(Bb, 3, 224, 224, device=dev) * 2 - 1
+    eb = torch.empty(Bb, 512, device=dev)
+    for _ in range(2):
+        mb.precompute_embedding_device(xb, eb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        mb.precompute_embedding_device(xb, eb)
+    torch.cuda.synchronize()
+    dtb = (time.perf_counter() - t0) / 4
+    out["vit_b32_image_embeds_per_sec"] = round(Bb / dtb, 1)
+    out["vit_b32_seconds_per_10k_crops"] = round(10000 / (Bb / dtb), 3)
+    mb.close()
+    del xb, eb
     # search: 125k x 768 f32 shard (1 M vectors over 8 GPUs), k=100, 1 query; HBM-bound scan of 384 MB
     N = 125_000
     ix = EmbeddingIndex(768, N, device=device_index)

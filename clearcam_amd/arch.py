@@ -87,6 +87,10 @@ class ClipArch:
 
 
 CLIP_L14 = ClipArch()
+# OpenAI / OpenCLIP ViT-B/32 (BASELINE.json's north star names it; the reference code itself instantiates ViT-L/14).
+# Same graph, different sizes: 7x7 patches + class token = 50 tokens, 12 heads of 64, 512-d joint space.
+CLIP_B32 = ClipArch(image_size=224, patch=32, v_width=768, v_layers=12, v_heads=12, v_mlp=3072,
+                    t_ctx=77, t_vocab=49408, t_width=512, t_layers=12, t_heads=8, t_mlp=2048, embed=512)
 # A shrunken tower with the same structure, for fast CPU/GPU unit tests.
 CLIP_TINY = ClipArch(image_size=56, patch=14, v_width=128, v_layers=2, v_heads=2, v_mlp=256,
                      t_ctx=77, t_vocab=512, t_width=64, t_layers=2, t_heads=1, t_mlp=128, embed=64)

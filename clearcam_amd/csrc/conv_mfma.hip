@@ -26,6 +26,12 @@
 // * Tiles are issued in an XCD-aware order (bijective remap of blockIdx): all channel tiles of a pixel tile and
 //   neighbouring pixel tiles run on one XCD's L2.
 // * f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32) with the k-slots of a 16-B chunk spread over 4 MFMAs.
+//
+// Kernels in this file, chosen per layer by launch_t():
+//   conv_mfma_kernel     the generic one described above (every shape, every dtype)
+//   conv_big_kernel      256x256 tile / 4 waves / one barrier per K step, for deep GEMM-shaped 16-bit layers
+//   conv3x3_halo_kernel  3x3 s1 with the input patch resident in LDS across the nine taps (128/256-channel layers)
+//   conv3x3_ws_kernel    3x3 s1 for narrow layers: persistent blocks, all nine taps of the weights resident in LDS
 #include <algorithm>
 #include <type_traits>
 #include "kernels.h"
@@ -34,9 +40,6 @@
 namespace cc {
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
-#ifndef CC_ABL
-#define CC_ABL 0   // compile-time ablation bits for timing experiments only (wrong results): 1 no DMA, 2 no ds_read, 4 no MFMA
-#endif
 
 struct ConvAux {
   float inv_hw, inv_wo;   // 1/(Ho*Wo), 1/Wo for divide-free pixel decomposition
@@ -350,7 +353,6 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  {
   // prologue: steps 0 .. NS-2 in flight
   int issued = 0;
 #pragma unroll
@@ -364,37 +366,22 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
     else if (NS > 2 && ahead >= 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __syncthreads();                                   // ... for every wave; the stage consumed at step kt-1 is free again
-    if (issued < nkt) { advance_k(); if (!(CC_ABL & 1)) issue_loads(st_i); ++issued; if (++st_i == NS) st_i = 0; }
+    if (issued < nkt) { advance_k(); issue_loads(st_i); ++issued; if (++st_i == NS) st_i = 0; }
     const uint4* ldsX = lds + st_c * STAGE;
     const uint4* ldsW = ldsX + BM * CPRW;
     if (++st_c == NS) st_c = 0;
 #pragma unroll
     for (int h = 0; h < CPRW / 4; ++h) {
       uint4 xf[MI], wf[NJ];
-      if constexpr (!(CC_ABL & 2)) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) { const int row = wm0 + i * 16 + fr; xf[i] = ldsX[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
+      for (int i = 0; i < MI; ++i) { const int row = wm0 + i * 16 + fr; xf[i] = ldsX[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { const int row = wn0 + j * 16 + fr; wf[j] = ldsW[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
-      } else {
+      for (int j = 0; j < NJ; ++j) { const int row = wn0 + j * 16 + fr; wf[j] = ldsW[row * CPRW + ((h * 4 + fg) ^ swz<CPRW>(row))]; }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) { xf[i] = make_uint4(kt + i, lane, h, 1); asm volatile("" : "+v"(xf[i].x), "+v"(xf[i].y), "+v"(xf[i].z), "+v"(xf[i].w)); }
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { wf[j] = make_uint4(kt + j, lane, h, 2); asm volatile("" : "+v"(wf[j].x), "+v"(wf[j].y), "+v"(wf[j].z), "+v"(wf[j].w)); }
-      }
-      if constexpr (!(CC_ABL & 4)) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int i = 0; i < MI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int i = 0; i < MI; ++i) { acc[j][i][0] += __uint_as_float(wf[j].x ^ xf[i].x); }
-      }
+        for (int i = 0; i < MI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
     }
-  }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from clearcam_amd.arch import CLIP_L14, CLIP_TINY
+from clearcam_amd.arch import CLIP_B32, CLIP_L14, CLIP_TINY
 from clearcam_amd.weights import synthetic_clip_state_dict
 from oracle.clip_oracle import OpenCLIPOracle, pad_tokens, search_reference
 
@@ -201,3 +201,19 @@ def test_store_backed_search_matches_reference_loop(tmp_path):
     g = ObjectFinder(base_path=str(base))                        # a fresh process finds everything on disk
     assert g.attach_store() == 140
     assert [p for p, _ in g.search(text_embedding=q)] == [p for p, _ in search_reference(ref_store, q)]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_clip_b32_matches_oracle(dtype):
+    """ViT-B/32 (the model BASELINE.json's north star names) through the same engine: 50 tokens, 12 heads, 512-d space."""
+    from clearcam_amd.objects import OpenCLIP
+    sd = synthetic_clip_state_dict(CLIP_B32, 99)
+    o = OpenCLIPOracle(sd, CLIP_B32)
+    m = OpenCLIP(state_dict=sd, arch=CLIP_B32, dtype=dtype)
+    x = np.random.default_rng(3).random((3, 3, 224, 224), dtype=np.float32) * 2 - 1
+    ref, got = o.precompute_embedding(x), m.precompute_embedding(x).numpy()
+    assert got.shape == (3, 512) and ((ref * got).sum(1) >= 1 - 1e-4).all()
+    toks = _toks(CLIP_B32)
+    assert ((o.encode_tokens(toks) * m.encode_tokens(toks)).sum(1) >= 1 - 1e-4).all()
+    if dtype == "f32":
+        assert np.abs(ref - got).max() < 1e-5
