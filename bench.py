@@ -133,6 +133,41 @@ def clip_side_metrics(device_index: int, dev) -> dict:
     return out
 
 
+def sharded_search_metrics(device_index: int, dev, world: int, rank: int) -> dict:
+    """BASELINE.json configs[4]: cross-camera search over a row-sharded index, 125 k x 768 f32 rows per GPU (1 M rows at
+    8 GPUs).  Every rank scans its shard (HBM), the per-rank top-k lists meet in ONE all-gather over RCCL/xGMI and are
+    merged on every rank (clearcam_amd/dist.py).  Latency = max over ranks of each rank's median, host-observed."""
+    import torch
+    import torch.distributed as dist
+    from clearcam_amd.dist import ShardedIndex
+    from clearcam_amd.objects import EmbeddingIndex
+    N = 125_000
+    ix = EmbeddingIndex(768, N, device=device_index)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    e = torch.randn(N, 768, device=dev, generator=g)
+    e /= e.norm(dim=1, keepdim=True)
+    ix.add(e)
+    sh = ShardedIndex(ix, device=dev)
+    q = torch.randn(1, 768, generator=torch.Generator().manual_seed(7))
+    q /= q.norm()
+    qn = q.numpy()
+    for _ in range(3):
+        ids, sc = sh.search(qn, 100)
+    lat = []
+    for _ in range(20):
+        dist.barrier()
+        t0 = time.perf_counter()
+        ids, sc = sh.search(qn, 100)
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
+    t = torch.tensor([lat[len(lat) // 2], lat[-1]], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = bool((np.diff(sc[0]) <= 0).all() and (ids[0] >= 0).all() and ids[0].max() < sh.total)
+    ix.close()
+    return {"rows_total": int(sh.total), "rows_per_gpu": N, "k": 100, "p50_ms": round(float(t[0]) * 1e3, 3),
+            "max_ms": round(float(t[1]) * 1e3, 3), "exchange_bytes_per_rank": 100 * 16, "result_sorted_and_in_range": ok}
+
+
 def stream_side_metrics(device_index: int, size: str, res: int, dtype: str) -> dict:
     """BASELINE.json configs[3]: synthetic 1080p cameras -> letterbox -> detect -> OC-SORT on one GPU, end to end
     INCLUDING the PCIe upload of every frame (pinned rings, async copies, two batches in flight; clearcam_amd/streams.py).
@@ -216,6 +251,17 @@ def main() -> None:
         elapsed = float(t.item())
     n_det = int((out[..., 4] > 0).sum().item())
 
+    sharded = None
+    if (world > 1 or os.environ.get("CLEARCAM_BENCH_FORCE_SHARDED")) and not args.no_clip:
+        model_was = model
+        try:                                     # side metric: must never take the headline line down with it
+            if world == 1 and not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+            sharded = sharded_search_metrics(local, dev, world, rank)
+        except Exception as exc:                 # noqa: BLE001
+            sharded = {"error": f"{type(exc).__name__}: {exc}"}
+        model = model_was
     if rank == 0:
         fps = world * B * args.steps / elapsed
         prof = model.profile(iters=3)
@@ -253,11 +299,14 @@ def main() -> None:
             line["streams"] = stream_side_metrics(local, args.size, args.res, args.dtype)
         if not args.no_clip:
             line["clip"] = clip_side_metrics(local, dev)
+        if sharded is not None:
+            line["search_sharded"] = sharded
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.size, args.res)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

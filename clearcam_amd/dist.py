@@ -51,12 +51,14 @@ def allgather_topk(local_idx, local_score, row_offset: int, k: int, group=None,
     idx = torch.as_tensor(np.asarray(local_idx), dtype=torch.int64, device=device)
     sc = torch.as_tensor(np.asarray(local_score), dtype=torch.float32, device=device)
     idx = torch.where(idx >= 0, idx + row_offset, idx)
+    # one message per rank: (Q, 2, k) int64 = [global ids | float32 score bits]
+    packed = torch.stack([idx, sc.view(torch.int32).to(torch.int64)], dim=1).contiguous()
     world = dist.get_world_size(group)
-    gi = [torch.empty_like(idx) for _ in range(world)]
-    gs = [torch.empty_like(sc) for _ in range(world)]
-    dist.all_gather(gi, idx, group=group)
-    dist.all_gather(gs, sc, group=group)
-    mi, ms = merge_topk(torch.cat(gi, 1), torch.cat(gs, 1), k)
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(parts, packed, group=group)
+    gi = torch.cat([t[:, 0] for t in parts], 1)
+    gs = torch.cat([t[:, 1].to(torch.int32).view(torch.float32) for t in parts], 1)
+    mi, ms = merge_topk(gi, gs, k)
     return mi.cpu().numpy(), ms.cpu().numpy()
 
 
