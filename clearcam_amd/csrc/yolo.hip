@@ -417,7 +417,60 @@ struct Builder {
     head(M + "22.", feats);
   }
 
+  // Arena packing: a buffer lives from the first launch that touches it to the last; buffers whose lifetimes do not
+  // overlap share memory (first-fit over buffers sorted by first use).  The letterboxed input and every tensor a
+  // parity tap can ask for stay live to the end.  YOLOv9-C, B=64, 640x640, bf16: 12 GB of tensors -> ~3 GB of arena.
+  // CLEARCAM_ARENA_REUSE=0 gives every buffer its own range (debugging).
+  void pack_arena() {
+    const char* e = getenv("CLEARCAM_ARENA_REUSE");
+    if (e && atoi(e) == 0) return;
+    const int nb = (int)P->bufs.size(), nops = (int)P->ops.size();
+    std::vector<int> first(nb, nops + 1), last(nb, -2);
+    auto touch = [&](const void* id, int t) {
+      const intptr_t i = (intptr_t)id;
+      if (i < 0 || i >= nb) return;
+      first[i] = std::min(first[i], t); last[i] = std::max(last[i], t);
+    };
+    for (int t = 0; t < nops; ++t) {
+      const Op& op = P->ops[t];
+      if (op.kind == 0) { touch(op.conv.s0.ptr, t); touch(op.conv.s1.ptr, t); touch(op.conv.out, t); touch(op.conv.res, t); }
+      else if (op.kind == 1) { touch(op.pool.in, t); touch(op.pool.out, t); }
+      else if (op.kind == 2) { for (int l = 0; l < 3; ++l) touch(op.dec.raw[l], t); }
+      else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) touch(op.fuse.in[k], t); touch(op.fuse.out, t); }
+    }
+    first[P->in_buf] = -1;                                     // written by the letterbox kernel before the first op
+    for (auto& kv : P->taps) last[kv.second] = nops + 1;       // cc_yolo_get_tensor reads these after the run
+    for (int i = 0; i < nb; ++i) if (last[i] < first[i]) { first[i] = -1; last[i] = nops + 1; }   // never touched: keep apart
+    auto bytes_of = [&](int i) {
+      const Buf& b = P->bufs[i];
+      const size_t n = (size_t)P->B * b.H * b.W * b.C * (b.f32 ? 4 : dtype_size(Y->dtype));
+      return (n + 255) & ~(size_t)255;
+    };
+    std::vector<int> order(nb);
+    for (int i = 0; i < nb; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return first[x] < first[y]; });
+    std::vector<int> placed;
+    size_t top = 0;
+    for (int i : order) {
+      const size_t need = bytes_of(i);
+      // candidate offsets: 0 and the end of every placed buffer that is alive at the same time
+      std::vector<std::pair<size_t, size_t>> busy;             // [off, end) of time-overlapping buffers
+      for (int j : placed) if (!(last[j] < first[i] || last[i] < first[j])) busy.emplace_back(P->bufs[j].off, P->bufs[j].off + bytes_of(j));
+      std::sort(busy.begin(), busy.end());
+      size_t off = 0;
+      for (auto& b : busy) { if (off + need <= b.first) break; off = std::max(off, b.second); }
+      P->bufs[i].off = off;
+      placed.push_back(i);
+      top = std::max(top, off + need);
+    }
+    if (getenv("CLEARCAM_VERBOSE"))
+      fprintf(stderr, "[clearcam] plan B=%d %dx%d: %d tensors, %.2f GB unpacked -> %.2f GB arena\n", P->B, P->Hn, P->Wn, nb,
+              (double)P->arena_bytes / 1e9, (double)top / 1e9);
+    P->arena_bytes = top;
+  }
+
   void resolve() {
+    pack_arena();
     CC_HIP(hipMalloc((void**)&P->arena, P->arena_bytes));
     CC_HIP(hipMemset(P->arena, 0, P->arena_bytes));
     CC_HIP(hipMalloc((void**)&P->det, (size_t)P->B * P->A * 6 * 4));
