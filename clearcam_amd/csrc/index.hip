@@ -170,6 +170,14 @@ void upload_queries(cc_index* h, const float* q, int Q, int on_device, hipStream
 
 void compute_scores(cc_index* h, int Q, hipStream_t s) {
   ensure((void**)&h->scores, &h->scores_cap, (size_t)Q * h->n * 4);
+  // More than four queries: one pass over the matrix as a GEMM on the exact-f32 MFMA path (queries = the 128-row tile,
+  // index rows = output channels, so every embedding is read from HBM once and scores come out (Q, N) row-major).
+  // Sixteen GEMV passes for 64 queries become one.  Products are exact f32 either way; only the summation order differs
+  // from the GEMV kernel (last-bit differences between the two paths).
+  if (Q > 4 && h->n % 4 == 0 && h->dim % 32 == 0) {
+    const ConvP g = gemm_params(h->q_dev, h->dim, Q, h->dim, h->emb, h->dim, nullptr, (int)h->n, h->scores, (int)h->n, 1, 0, nullptr, 0, 0);
+    if (h->n < (1L << 31) && conv_mfma_supported(F32, g)) { launch_conv_mfma(F32, g, s); return; }
+  }
   const int blocks = (int)std::min<int64_t>((h->n + 3) / 4, 256 * 16);
   for (int q0 = 0; q0 < Q; q0 += 4) {
     const int nq = std::min(4, Q - q0);

@@ -217,3 +217,22 @@ def test_clip_b32_matches_oracle(dtype):
     assert ((o.encode_tokens(toks) * m.encode_tokens(toks)).sum(1) >= 1 - 1e-4).all()
     if dtype == "f32":
         assert np.abs(ref - got).max() < 1e-5
+
+
+def test_multi_query_scan_matches_single_query_path():
+    """Q > 4 queries go through one GEMM pass over the index (exact-f32 MFMA) instead of ceil(Q/4) GEMV passes: same
+    scores to f32 rounding, same top-k semantics (stable descending order of the returned scores)."""
+    from clearcam_amd.objects import EmbeddingIndex
+    rng = np.random.default_rng(11)
+    E = rng.standard_normal((50000, 768)).astype(np.float32); E /= np.linalg.norm(E, axis=1, keepdims=True)
+    Q = rng.standard_normal((64, 768)).astype(np.float32); Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    ix = EmbeddingIndex(768, 50000); ix.add(E)
+    many = ix.scores(Q)                                                    # GEMM path
+    single = np.concatenate([ix.scores(Q[i:i + 1]) for i in range(0, 64, 16)])       # GEMV path on a few rows
+    assert np.abs(many - Q @ E.T).max() < 1e-6
+    assert np.abs(many[::16] - single).max() < 1e-6
+    idx, s = ix.search(Q, 100)
+    order = np.argsort(-many, axis=1, kind="stable")[:, :100]
+    assert np.array_equal(idx, order) and np.array_equal(s, np.take_along_axis(many, order, 1))
+    odd = EmbeddingIndex(768, 50001); odd.add(E); odd.add(E[:1])             # N % 4 != 0 -> GEMV passes, same answers
+    assert np.abs(odd.scores(Q[:8])[:, :50000] - many[:8]).max() < 1e-6
