@@ -72,3 +72,40 @@ class ShardedIndex:
     def search(self, q, k: int):
         idx, sc = self.index.search(q, k)
         return allgather_topk(idx, sc, self.row_offset, k, self.group, self.device)
+
+
+def allgather_rows(rows: torch.Tensor, group=None) -> Tuple[torch.Tensor, Sequence[int]]:
+    """Pool newly computed embeddings: every rank contributes its (n_r, dim) rows (n_r may differ, may be 0) and receives
+    the concatenation in rank order plus the per-rank counts.  One size exchange + one padded all-gather (RCCL over xGMI
+    with CUDA tensors).  This is the "replicated index" alternative of SURVEY.md §8e: a camera's crops are encoded on its
+    own GPU, then every GPU appends everybody's rows, so any rank can answer a cross-camera query alone.  At 768 f32 a
+    batch of 256 crops per rank is 0.8 MB per rank per exchange; replicating a whole 1 M-row index this way costs 3 GB
+    through a per-link-bound ring, which is why steady-state search uses ShardedIndex (top-k exchange) instead."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    padded = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    padded[:rows.shape[0]] = rows
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], 0), counts
+
+
+class ReplicatedIndex:
+    """Every rank holds every row: `add_local(rows)` pools this step's new embeddings from all ranks (allgather_rows) and
+    appends them in rank order, so row ids agree everywhere; `search` is purely local."""
+
+    def __init__(self, index, group=None):
+        self.index, self.group = index, group
+
+    def add_local(self, rows: torch.Tensor) -> Sequence[int]:
+        allrows, counts = allgather_rows(rows, self.group)
+        if allrows.shape[0]:
+            self.index.add(allrows)
+        return counts
+
+    def search(self, q, k: int):
+        return self.index.search(q, k)

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from clearcam_amd.dist import allgather_topk, camera_rank, merge_topk, shard_offsets
+from clearcam_amd.dist import ReplicatedIndex, allgather_rows, allgather_topk, camera_rank, merge_topk, shard_offsets
 
 
 def _free_port():
@@ -46,6 +46,47 @@ def test_sharded_topk_allgather_gloo_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get(0) is True and ret.get(1) is True
+
+
+class _HostIndex:                                              # stands in for the HBM matrix: gloo workers have no GPU
+    def __init__(self):
+        self.rows = np.zeros((0, 8), np.float32)
+
+    def add(self, r):
+        self.rows = np.concatenate([self.rows, np.asarray(r, np.float32)])
+
+    def search(self, q, k):
+        sc = q @ self.rows.T
+        o = np.argsort(-sc, axis=1, kind="stable")[:, :k]
+        return o, np.take_along_axis(sc, o, 1)
+
+
+def _worker_rows(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ri = ReplicatedIndex(_HostIndex())
+        ok = True
+        for step, sizes in enumerate([(3, 5), (0, 2), (4, 0), (0, 0)]):          # ragged and empty contributions
+            mine = torch.full((sizes[rank], 8), float(10 * step + rank))
+            counts = ri.add_local(mine)
+            ok &= list(counts) == list(sizes)
+        expect = np.concatenate([np.full((n, 8), 10.0 * step + r, np.float32)
+                                 for step, sizes in enumerate([(3, 5), (0, 2), (4, 0), (0, 0)]) for r, n in enumerate(sizes)])
+        ok &= np.array_equal(ri.index.rows, expect)                              # same rows, same order on every rank
+        rows, counts = allgather_rows(torch.arange(rank * 6, rank * 6 + 6, dtype=torch.float32).reshape(3, 2))
+        ok &= rows.flatten().tolist() == list(map(float, range(12))) and list(counts) == [3, 3]
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pooled_embeddings_replicated_index_gloo_world2():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_rows, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret.get(0) is True and ret.get(1) is True
 
 
