@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvP p) {
   float t = acc + (p.bias ? p.bias[n] : 0.f);
   if (p.act == 1) t = t / (1.0f + expf(-t));
   else if (p.act == 2) t = 0.5f * t * (1.0f + tanhf(0.7978845608028654f * (t + 0.044715f * t * t * t)));
+  else if (p.act == 3) t = t > 0.f ? t : p.slope[n] * t;
   if (p.res) {
     const size_t ri = m * p.res_cstride + p.res_coff + n;
     t = (p.res_f32 ? reinterpret_cast<const float*>(p.res)[ri] : to_f32<T>(reinterpret_cast<const T*>(p.res)[ri])) + t;

@@ -124,13 +124,15 @@ __device__ __forceinline__ void stage_tile(const ConvP& p, const f32x4 (&acc)[NJ
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int nl = wn0 + j * 16 + fg * 4, n = n0 + nl;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n < p.Cout) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    if constexpr (ACT == 3) { if (n < p.Cout) s4 = *reinterpret_cast<const float4*>(p.slope + n); }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const f32x4 av = acc[j][i];
-      const float v0 = activate<T, ACT>(av[0] + b4.x), v1 = activate<T, ACT>(av[1] + b4.y);
-      const float v2 = activate<T, ACT>(av[2] + b4.z), v3 = activate<T, ACT>(av[3] + b4.w);
+      float v0 = activate<T, ACT>(av[0] + b4.x), v1 = activate<T, ACT>(av[1] + b4.y);
+      float v2 = activate<T, ACT>(av[2] + b4.z), v3 = activate<T, ACT>(av[3] + b4.w);
+      if constexpr (ACT == 3) { v0 = v0 > 0.f ? v0 : s4.x * v0; v1 = v1 > 0.f ? v1 : s4.y * v1; v2 = v2 > 0.f ? v2 : s4.z * v2; v3 = v3 > 0.f ? v3 : s4.w * v3; }
       const int row = wm0 + i * 16 + fr;
       const int ch = (nl >> 3) ^ (rowswz(row) & (CPR - 1));
       *reinterpret_cast<uint2*>(tilep + row * ROWB + ch * 16 + (nl & 4) * 2) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
@@ -146,8 +148,9 @@ __device__ __forceinline__ void direct_tile(const ConvP& p, const f32x4 (&acc)[N
   for (int j = 0; j < NJ; ++j) {
     const int n = nbase + j * 16;
     const bool nok = n < p.Cout;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && nok) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+    if constexpr (ACT == 3) { if (nok) { const float4 s4 = *reinterpret_cast<const float4*>(p.slope + n); sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w; } }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const f32x4 av = acc[j][i];
@@ -155,7 +158,10 @@ __device__ __forceinline__ void direct_tile(const ConvP& p, const f32x4 (&acc)[N
       if (nok && m >= 0) {
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = activate<T, ACT>(av[e] + bv[e]);
+        for (int e = 0; e < 4; ++e) {
+          v[e] = activate<T, ACT>(av[e] + bv[e]);
+          if constexpr (ACT == 3) v[e] = v[e] > 0.f ? v[e] : sv[e] * v[e];
+        }
         if (p.res) {
           float rv[4];
           const size_t ri = (size_t)m * p.res_cstride + p.res_coff + n;
@@ -189,6 +195,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][M
       char* tilep = reinterpret_cast<char*>(lds);
       if (p.act == 1) stage_tile<T, 1, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
       else if (p.act == 2) stage_tile<T, 2, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
+      else if (p.act == 3) stage_tile<T, 3, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
       else stage_tile<T, 0, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
       __syncthreads();
       T* outp = reinterpret_cast<T*>(p.out) + p.out_coff + n0;
@@ -209,6 +216,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][M
   for (int i = 0; i < MI; ++i) mrow[i] = pix(wm0 + i * 16 + fr);
   if (p.act == 1) direct_tile<T, 1, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
   else if (p.act == 2) direct_tile<T, 2, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
+  else if (p.act == 3) direct_tile<T, 3, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
   else direct_tile<T, 0, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
 }
 

@@ -249,3 +249,50 @@ def load_safetensors(path: str) -> Dict[str, np.ndarray]:
     from safetensors.numpy import load_file
     return {k: np.ascontiguousarray(v, dtype=np.float32) if v.dtype != np.float32 else v
             for k, v in load_file(path).items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# AdaFace IR-50 (models/adaface.py)
+# ----------------------------------------------------------------------------------------------
+ADAFACE_BLOCKS = [(64, 64, 2), (64, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 1), (128, 128, 1), (128, 128, 1), (128, 256, 2)] + \
+                 [(256, 256, 1)] * 13 + [(256, 512, 2), (512, 512, 1), (512, 512, 1)]
+
+
+def synthetic_adaface_state_dict(seed: int = 777) -> Dict[str, np.ndarray]:
+    """Seeded IR-50 state dict with the reference's parameter names (tinygrad get_state_dict of models/adaface.py:61-76).
+    He-scaled zero-sum conv filters; BatchNorm statistics near (0, 1) with mild per-channel spread so that folding
+    mistakes show; the residual branch is damped so that 24 blocks keep O(1) activations."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    def conv(co, ci, k, gain=1.0):
+        w = rng.standard_normal((co, ci, k, k), dtype=np.float32)
+        w -= w.mean(axis=(1, 2, 3), keepdims=True)
+        return (w * np.float32(gain * math.sqrt(2.0 / (ci * k * k)))).astype(np.float32)
+
+    def bn(sd, p, c, affine=True, wscale=1.0):
+        if affine:
+            sd[p + ".weight"] = (wscale * (1.0 + 0.1 * rng.standard_normal(c))).astype(np.float32)
+            sd[p + ".bias"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+        sd[p + ".running_mean"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+        sd[p + ".running_var"] = (1.0 + 0.2 * rng.random(c)).astype(np.float32)
+
+    sd: Dict[str, np.ndarray] = {}
+    sd["conv0.weight"] = conv(64, 3, 3)
+    bn(sd, "bn0", 64)
+    sd["prelu_weight"] = (0.25 + 0.05 * rng.standard_normal(64)).astype(np.float32)
+    for i, (cin, depth, stride) in enumerate(ADAFACE_BLOCKS):
+        p = f"body.list.{i}."
+        bn(sd, p + "res_layer0", cin)
+        sd[p + "conv_layer0.weight"] = conv(depth, cin, 3)
+        bn(sd, p + "res_layer1", depth)
+        sd[p + "prelu_weight"] = (0.25 + 0.05 * rng.standard_normal(depth)).astype(np.float32)
+        sd[p + "conv_layer1.weight"] = conv(depth, depth, 3)
+        bn(sd, p + "res_layer2", depth, wscale=0.5)
+        if cin != depth:
+            sd[p + "shortcut_layer0.weight"] = conv(depth, cin, 1, gain=0.7)
+            bn(sd, p + "shortcut_layer1", depth)
+    bn(sd, "bn", 512)
+    sd["linear.weight"] = (rng.standard_normal((512, 512 * 7 * 7), dtype=np.float32) * np.float32(1.0 / math.sqrt(512 * 49))).astype(np.float32)
+    sd["linear.bias"] = (0.01 * rng.standard_normal(512)).astype(np.float32)
+    bn(sd, "bn2", 512, affine=False)
+    return sd

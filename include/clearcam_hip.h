@@ -100,6 +100,20 @@ int cc_crop_preprocess(const uint8_t* pixels, const int64_t* offsets, const int3
                        int B, int pixels_on_device, int out_size, float* out_dev, int device, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * AdaFace IR-50 face embedder — stands behind `ADAFACE.__call__(x)` (models/adaface.py:79-95), called as
+ * `object_finder.adaface(Tensor(face_img))` (clearcam.py:674,1236) on a 112x112x3 aligned face.
+ * Parameters by the reference's state-dict names (conv0.weight, bn0.*, prelu_weight, body.list.<i>.*, bn.*,
+ * linear.*, bn2.running_*).  faces: (B,112,112,3) uint8 or float32 in the order the reference receives them
+ * (it flips [:,:,::-1] itself) -> out (B,512) float32, each row x / ||x||_2.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cc_face cc_face;
+int cc_face_create(cc_face** h, int dtype, int device);
+int cc_face_load(cc_face* h, const char* name, const float* data, const int64_t* shape, int ndim);
+int cc_face_finalize(cc_face* h);
+int cc_face_embed(cc_face* h, const void* faces, int B, int img_f32, int faces_on_device, float* out, int out_on_device, void* stream);
+void cc_face_destroy(cc_face* h);
+
+/* ---------------------------------------------------------------------------------------------
  * OC-SORT tracker (host code, no GPU) — stands behind `OCSort(...)` / `OCSort.update(preds, thresh)`
  * (ocsort_tracker/ocsort.py:164-308), the consumer of the detector output (clearcam.py:239,585).
  * dets: n rows [x1,y1,x2,y2,score,class] float32 exactly as cc_yolo_detect writes them (zero rows allowed).

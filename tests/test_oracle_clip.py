@@ -120,3 +120,20 @@ def test_cubic_resize_oracle_properties():
     p = preprocess(a)
     assert p.shape == (3, 224, 224) and p.dtype == np.float32 and p.min() >= -1 and p.max() <= 1
     assert p[0, 0, 0] == np.float32((np.float32(a[0, 0, 0]) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5))
+
+
+def test_adaface_oracle_structure():
+    """IR-50 as models/adaface.py builds it: 24 blocks (3, 4, 14, 3 per stage), 43.6 M parameters, 7x7x512 features,
+    unit-norm 512-d output that depends on the input."""
+    from clearcam_amd.weights import ADAFACE_BLOCKS, synthetic_adaface_state_dict
+    from oracle.adaface_oracle import BLOCKS, AdaFaceOracle
+    assert BLOCKS == ADAFACE_BLOCKS and len(BLOCKS) == 24 and [b[2] for b in BLOCKS].count(2) == 4
+    sd = synthetic_adaface_state_dict(777)
+    assert abs(sum(v.size for v in sd.values()) / 1e6 - 43.62) < 0.05
+    o = AdaFaceOracle(sd)
+    rng = np.random.default_rng(0)
+    a, b = (rng.integers(0, 256, (112, 112, 3), dtype=np.uint8) for _ in range(2))
+    ea, eb = o(a), o(b)
+    assert ea.shape == (1, 512) and abs(np.linalg.norm(ea) - 1) < 1e-5 and float((ea @ eb.T)[0, 0]) < 0.9
+    assert np.array_equal(o(a), ea) and tuple(o.features(a).shape) == (1, 512, 7, 7)
+    assert np.abs(o(a.astype(np.float32)) - ea).max() < 1e-6               # uint8 and float inputs agree
