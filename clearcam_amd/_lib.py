@@ -14,6 +14,7 @@ SYMBOLS = [
     "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_destroy", "cc_conv2d_nhwc",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
     "cc_clip_last_gpu_ms", "cc_clip_destroy", "cc_crop_preprocess",
+    "cc_blaze_create", "cc_blaze_load", "cc_blaze_finalize", "cc_blaze_detect", "cc_blaze_destroy",
     "cc_face_create", "cc_face_load", "cc_face_finalize", "cc_face_embed", "cc_face_destroy",
     "cc_ocsort_create", "cc_ocsort_update", "cc_ocsort_update_many", "cc_ocsort_num_tracks", "cc_ocsort_destroy",
     "cc_index_create", "cc_index_add", "cc_index_size", "cc_index_scores", "cc_index_search", "cc_index_destroy",
@@ -68,6 +69,10 @@ def lib() -> C.CDLL:
         "cc_clip_encode_text": [vp, vp, C.c_int, vp, C.c_int, vp],
         "cc_clip_last_gpu_ms": [vp, fp],
         "cc_crop_preprocess": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
+        "cc_blaze_create": [C.POINTER(vp), C.c_int, C.c_int],
+        "cc_blaze_load": [vp, C.c_char_p, vp, i64p, C.c_int],
+        "cc_blaze_finalize": [vp],
+        "cc_blaze_detect": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_face_create": [C.POINTER(vp), C.c_int, C.c_int],
         "cc_face_load": [vp, C.c_char_p, vp, i64p, C.c_int],
         "cc_face_finalize": [vp],
@@ -86,7 +91,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
-    for name in ("cc_yolo_destroy", "cc_clip_destroy", "cc_index_destroy", "cc_ocsort_destroy", "cc_face_destroy"):
+    for name in ("cc_yolo_destroy", "cc_clip_destroy", "cc_index_destroy", "cc_ocsort_destroy", "cc_face_destroy", "cc_blaze_destroy"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = None
     _lib = L

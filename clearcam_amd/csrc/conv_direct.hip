@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvP p) {
     const size_t ri = m * p.res_cstride + p.res_coff + n;
     t = (p.res_f32 ? reinterpret_cast<const float*>(p.res)[ri] : to_f32<T>(reinterpret_cast<const T*>(p.res)[ri])) + t;
   }
+  if (p.act == 4) t = fmaxf(t, 0.f);
   const size_t oi = m * p.out_cstride + p.out_coff + n;
   if (p.out_f32) reinterpret_cast<float*>(p.out)[oi] = t;
   else reinterpret_cast<T*>(p.out)[oi] = from_f32<T>(t);

@@ -133,6 +133,7 @@ __device__ __forceinline__ void stage_tile(const ConvP& p, const f32x4 (&acc)[NJ
       float v0 = activate<T, ACT>(av[0] + b4.x), v1 = activate<T, ACT>(av[1] + b4.y);
       float v2 = activate<T, ACT>(av[2] + b4.z), v3 = activate<T, ACT>(av[3] + b4.w);
       if constexpr (ACT == 3) { v0 = v0 > 0.f ? v0 : s4.x * v0; v1 = v1 > 0.f ? v1 : s4.y * v1; v2 = v2 > 0.f ? v2 : s4.z * v2; v3 = v3 > 0.f ? v3 : s4.w * v3; }
+      if constexpr (ACT == 4) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }   // staged path has no residual
       const int row = wm0 + i * 16 + fr;
       const int ch = (nl >> 3) ^ (rowswz(row) & (CPR - 1));
       *reinterpret_cast<uint2*>(tilep + row * ROWB + ch * 16 + (nl & 4) * 2) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
@@ -169,6 +170,10 @@ __device__ __forceinline__ void direct_tile(const ConvP& p, const f32x4 (&acc)[N
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
         }
+        if constexpr (ACT == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         const size_t oi = (size_t)m * p.out_cstride + p.out_coff + n;
         if (p.out_f32) store4<float>(p.out, oi, v); else store4<T>(p.out, oi, v);
       }
@@ -196,6 +201,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][M
       if (p.act == 1) stage_tile<T, 1, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
       else if (p.act == 2) stage_tile<T, 2, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
       else if (p.act == 3) stage_tile<T, 3, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
+      else if (p.act == 4) stage_tile<T, 4, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
       else stage_tile<T, 0, BN, MI, NJ>(p, acc, tilep, n0, wm0, wn0, fr, fg);
       __syncthreads();
       T* outp = reinterpret_cast<T*>(p.out) + p.out_coff + n0;
@@ -217,6 +223,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][M
   if (p.act == 1) direct_tile<T, 1, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
   else if (p.act == 2) direct_tile<T, 2, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
   else if (p.act == 3) direct_tile<T, 3, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
+  else if (p.act == 4) direct_tile<T, 4, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
   else direct_tile<T, 0, MI, NJ>(p, acc, mrow, n0 + wn0 + fg * 4);
 }
 

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
   const int x = (int)(idx % p.Wn);
   const int y = (int)((idx / p.Wn) % p.Hn);
   const int b = (int)(idx / ((size_t)p.Wn * p.Hn));
-  float rgb[3] = {0.f, 0.f, 0.f};
+  float rgb[3] = {p.pad_val, p.pad_val, p.pad_val};
   const int yy = y - p.pad_y, xx = x - p.pad_x;
   if ((unsigned)yy < (unsigned)p.nh && (unsigned)xx < (unsigned)p.nw) {
     const int x0 = p.xlo[xx], x1 = p.xhi[xx], y0 = p.ylo[yy], y1 = p.yhi[yy];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
       for (int c = 0; c < 3; ++c) {
         const int top = lerp_u8(f[(r0 + x0) * 3 + c], f[(r0 + x1) * 3 + c], wx);
         const int bot = lerp_u8(f[(r1 + x0) * 3 + c], f[(r1 + x1) * 3 + c], wx);
-        rgb[2 - c] = __fdiv_rn((float)lerp_u8(top, bot, wy), 255.0f);
+        rgb[p.flip ? 2 - c : c] = __fsub_rn(__fdiv_rn((float)lerp_u8(top, bot, wy), p.div), p.sub);
       }
     } else {
       const float* f = reinterpret_cast<const float*>(p.frames);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
         const float a1 = f[(r1 + x0) * 3 + c], b1 = f[(r1 + x1) * 3 + c];
         const float top = __fadd_rn(a0, __fmul_rn(__fsub_rn(b0, a0), fx));
         const float bot = __fadd_rn(a1, __fmul_rn(__fsub_rn(b1, a1), fx));
-        rgb[2 - c] = __fdiv_rn(__fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), fy)), 255.0f);
+        rgb[p.flip ? 2 - c : c] = __fsub_rn(__fdiv_rn(__fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), fy)), p.div), p.sub);
       }
     }
   }

@@ -16,14 +16,13 @@
 #include <string>
 #include <vector>
 #include <cstring>
-#include "kernels.h"
+#include "net_common.h"
 #include "../../include/clearcam_hip.h"
 
 using namespace cc;
 
 namespace {
 
-struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 constexpr float kEps = 1e-5f;
 constexpr int kRes = 112;
 const int kBlocks[24][3] = {{64, 64, 2}, {64, 64, 1}, {64, 64, 1}, {64, 128, 2}, {128, 128, 1}, {128, 128, 1}, {128, 128, 1}, {128, 256, 2},
@@ -31,7 +30,6 @@ const int kBlocks[24][3] = {{64, 64, 2}, {64, 64, 1}, {64, 64, 1}, {64, 128, 2},
                             {256, 256, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1}, {256, 256, 1},
                             {256, 512, 2}, {512, 512, 1}, {512, 512, 1}};   // models/adaface.py:58
 
-struct PConv { void* w = nullptr; float* bias = nullptr; float* slope = nullptr; int cin = 0, cout = 0, k = 0, kw = 0; };
 struct Affine { float* scale = nullptr; float* shift = nullptr; int c = 0; };
 struct FBlock { Affine pre; PConv c0, c1, sc; int cin, depth, stride; };
 
@@ -97,13 +95,7 @@ const HostTensor& need(cc_face* h, const std::string& name) {
   CC_CHECK(it != h->host.end(), "missing parameter " + name);
   return it->second;
 }
-float* upload(cc_face* h, const std::vector<float>& v) {
-  float* d = nullptr;
-  CC_HIP(hipMalloc((void**)&d, v.size() * 4 + 256));
-  CC_HIP(hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
-  h->wallocs.push_back(d);
-  return d;
-}
+float* upload(cc_face* h, const std::vector<float>& v) { return upload_f32(h->wallocs, v); }
 // inference BatchNorm as y = x * s + t
 void bn_st(cc_face* h, const std::string& p, int c, bool affine, std::vector<float>& s, std::vector<float>& t) {
   const HostTensor& mean = need(h, p + ".running_mean"); const HostTensor& var = need(h, p + ".running_var");
@@ -119,43 +111,13 @@ Affine make_affine(cc_face* h, const std::string& p, int c) {
   std::vector<float> s, t; bn_st(h, p, c, true, s, t);
   return Affine{upload(h, s), upload(h, t), c};
 }
-// OIHW conv (no bias) followed by BatchNorm `bn` -> [Cout][k][k][cin_pad] in the storage dtype (rows padded to 64) + f32 bias
+// OIHW conv (no bias) followed by BatchNorm `bn`: scale folded into the rows, shift becomes the bias; optional PReLU slopes
 PConv make_conv(cc_face* h, const std::string& wname, const std::string& bn, const std::string& prelu, int cin_pad = 0) {
   const HostTensor& w = need(h, wname);
-  CC_CHECK(w.shape.size() == 4 && w.shape[2] == w.shape[3], wname + " must be OIHW");
-  const int co = (int)w.shape[0], ci = (int)w.shape[1], k = (int)w.shape[2];
-  const int cp = cin_pad > ci ? cin_pad : ci;
-  std::vector<float> s, t; bn_st(h, bn, co, true, s, t);
-  const size_t kreal = (size_t)k * k * cp, kw = (kreal + 63) / 64 * 64;
-  std::vector<float> packed((size_t)co * kw, 0.f);
-  for (int n = 0; n < co; ++n)
-    for (int c = 0; c < ci; ++c)
-      for (int r = 0; r < k; ++r)
-        for (int q = 0; q < k; ++q)
-          packed[(size_t)n * kw + (size_t)(r * k + q) * cp + c] = w.data[(((size_t)n * ci + c) * k + r) * k + q] * s[n];
-  PConv pc; pc.cin = cp; pc.cout = co; pc.k = k; pc.kw = (int)kw;
-  std::vector<char> tmp(packed.size() * dtype_size(h->dtype));
-  convert_f32_to(h->dtype, packed.data(), tmp.data(), packed.size());
-  CC_HIP(hipMalloc(&pc.w, tmp.size() + 256));
-  CC_HIP(hipMemcpy(pc.w, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
-  h->wallocs.push_back(pc.w);
-  pc.bias = upload(h, t);
-  if (!prelu.empty()) { const HostTensor& a = need(h, prelu); CC_CHECK((int)a.data.size() == co, prelu + " size"); pc.slope = upload(h, a.data); }
+  std::vector<float> s, t; bn_st(h, bn, (int)w.shape[0], true, s, t);
+  PConv pc = pack_conv(h->dtype, h->wallocs, w, 1, s, t, cin_pad);
+  if (!prelu.empty()) { const HostTensor& a = need(h, prelu); CC_CHECK((int)a.data.size() == pc.cout, prelu + " size"); pc.slope = upload(h, a.data); }
   return pc;
-}
-
-ConvP conv_params(const PConv& pc, const void* x, int B, int H, int W, int stride, void* out, int act, const void* res) {
-  ConvP c{};
-  c.s0 = Src{x, H, W, pc.cin, 0, pc.cin, 0};
-  c.s1 = Src{x, 1, 1, 0, 0, 0, 0};
-  c.B = B; c.Hin = H; c.Win = W; c.Cin = pc.cin;
-  c.ks = pc.k; c.stride = stride; c.pad = pc.k / 2;
-  c.Ho = (H + 2 * c.pad - pc.k) / stride + 1; c.Wo = (W + 2 * c.pad - pc.k) / stride + 1;
-  c.Cout = pc.cout; c.Ktot = pc.k * pc.k * pc.cin; c.Kw = pc.kw; c.w = pc.w; c.bias = pc.bias;
-  c.out = out; c.out_cstride = pc.cout; c.out_coff = 0; c.out_f32 = 0;
-  c.res = res; c.res_cstride = pc.cout; c.res_coff = 0; c.res_f32 = 0;
-  c.act = act; c.slope = pc.slope;
-  return c;
 }
 
 void run_ops(cc_face* h, FPlan* P, hipStream_t s) {
@@ -192,7 +154,7 @@ FPlan* get_plan(cc_face* h, int B, int img_f32) {
   const size_t es = dtype_size(h->dtype);
   auto act_buf = [&](int H, int W, int C) { return P->alloc((size_t)B * H * W * C * es); };
   auto add_conv = [&](const PConv& pc, const void* x, int H, int W, int stride, void* out, int act, const void* res) {
-    FOp op{}; op.kind = 0; op.conv = conv_params(pc, x, B, H, W, stride, out, act, res); P->ops.push_back(op);
+    FOp op{}; op.kind = 0; op.conv = conv_params(pc, x, B, H, W, stride, out, pc.cout, 0, act, res, pc.cout); P->ops.push_back(op);
   };
   auto add_affine = [&](const Affine& a, const void* x, void* y, long n) {
     FOp op{}; op.kind = 2; op.af = AffineP{x, y, a.scale, a.shift, n, a.c}; P->ops.push_back(op);
@@ -232,15 +194,8 @@ FPlan* get_plan(cc_face* h, int B, int img_f32) {
     P->ops.push_back(op);
   }
   { FOp op{}; op.kind = 4; op.nm = NormP{P->out_dev, B, 512, 0.0f}; P->ops.push_back(op); }
-  // eager warm-up, then capture
-  run_ops(h, P.get(), h->stream);
-  CC_HIP(hipStreamSynchronize(h->stream));
-  hipGraph_t graph = nullptr;
-  CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-  try { run_ops(h, P.get(), h->stream); } catch (...) { hipStreamEndCapture(h->stream, &graph); if (graph) hipGraphDestroy(graph); throw; }
-  CC_HIP(hipStreamEndCapture(h->stream, &graph));
-  CC_HIP(hipGraphInstantiate(&P->exec, graph, nullptr, nullptr, 0));
-  CC_HIP(hipGraphDestroy(graph));
+  FPlan* pp = P.get();
+  P->exec = capture_graph(h->stream, [&]() { run_ops(h, pp, h->stream); });
   FPlan* raw = P.get();
   h->plans[key] = std::move(P);
   return raw;

@@ -1,5 +1,6 @@
 // Kernel launchers (one translation unit per family).  All launches are asynchronous on `stream`.
 #pragma once
+#include <vector>
 #include "common.h"
 
 namespace cc {
@@ -41,9 +42,13 @@ struct PreP {                 // letterbox: detection/yolov9.py:376-379,390-404
   int nh, nw, pad_y, pad_x, Hn, Wn;       // resized dims, padding, network dims
   const int* xlo; const int* xhi; const float* xfr;   // per-axis interpolation tables (device)
   const int* ylo; const int* yhi; const float* yfr;
-  void* out; int out_c;                   // (B,Hn,Wn,out_c) storage dtype, RGB in ch 0..2, rest 0
+  void* out; int out_c;                   // (B,Hn,Wn,out_c) storage dtype, colour in ch 0..2, rest 0
+  int flip;                               // 1: BGR -> RGB (detector), 0: keep the channel order (BlazeFace)
+  float div, sub, pad_val;                // inside the image: v / div - sub; in the padding: pad_val
 };
 void launch_preprocess(int dt, const PreP& p, hipStream_t stream);
+// tinygrad `interpolate(mode='linear', align_corners=False)` index tables for one axis, evaluated in float32 (yolo.hip)
+void axis_tables(int n_in, int n_out, std::vector<int>& lo, std::vector<int>& hi, std::vector<float>& fr);
 
 struct DecodeP {              // DDetect decode + class max: detection/yolov9.py:209-220,440-448
   const float* raw[3]; int H[3], W[3];    // per level (B,H,W,144) f32

@@ -491,7 +491,7 @@ struct Builder {
 
 // tinygrad interpolate index tables in float32; mirrors oracle interp_axis_tables.
 #pragma clang fp contract(off)
-static void axis_tables(int n_in, int n_out, std::vector<int>& lo, std::vector<int>& hi, std::vector<float>& fr) {
+void axis_tables(int n_in, int n_out, std::vector<int>& lo, std::vector<int>& hi, std::vector<float>& fr) {
   lo.resize(n_out); hi.resize(n_out); fr.resize(n_out);
   const float scale = (float)((double)n_in / (double)n_out);
   for (int i = 0; i < n_out; ++i) {
@@ -650,6 +650,7 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
   pp.nh = P->nh; pp.nw = P->nw; pp.pad_y = P->pad_y; pp.pad_x = P->pad_x; pp.Hn = P->Hn; pp.Wn = P->Wn;
   pp.xlo = P->xlo; pp.xhi = P->xhi; pp.xfr = P->xfr; pp.ylo = P->ylo; pp.yhi = P->yhi; pp.yfr = P->yfr;
   pp.out = P->arena + P->bufs[P->in_buf].off; pp.out_c = P->bufs[P->in_buf].C;
+  pp.flip = 1; pp.div = 255.0f; pp.sub = 0.0f; pp.pad_val = 0.0f;          // [..., ::-1] and / 255.0 (detection/yolov9.py:377-379)
   launch_preprocess(h->dtype, pp, s);
   CC_HIP(hipGraphLaunch(P->exec, s));
   CC_HIP(hipEventRecord(h->ev1, s));

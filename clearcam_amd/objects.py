@@ -209,6 +209,28 @@ class ObjectFinder:
             self.model.close()
         self.model = None
 
+    # -- face models (:213-222): BlazeFace detector + AdaFace embedder on the same engine ------------------------
+    def init_face(self, blazeface_kwargs: Optional[dict] = None, adaface_kwargs: Optional[dict] = None):
+        """:213-217.  `self.blazeface(Tensor(img)).numpy()` -> (896,17) and `self.adaface(Tensor(face112)).numpy()` -> (1,512)
+        are the reference's two face call surfaces (objects.py:254, clearcam.py:674,1236).  The OpenCV similarity-warp
+        between them (`img_to_face`, objects.py:243-354) is host glue that is not mirrored yet."""
+        if getattr(self, "face", False):
+            return
+        from .adaface import ADAFACE
+        from .blazeface import BlazeFace
+        self.blazeface = BlazeFace(**(blazeface_kwargs or {}))
+        self.adaface = ADAFACE(**(adaface_kwargs or {}))
+        self.face = True
+
+    def turn_off_face(self):
+        """:219-222"""
+        for name in ("blazeface", "adaface"):
+            m = getattr(self, name, None)
+            if m is not None:
+                m.close()
+            setattr(self, name, None)
+        self.face = False
+
     def preprocess(self, img):
         """:237-242 — cv2.resize(img,(224,224),INTER_CUBIC) -> f32/255 -> (x-0.5)/0.5 -> CHW, on the GPU
         (cc_crop_preprocess: OpenCV's 8-bit fixed-point cubic).  Returns (3,224,224) float32 like the reference."""

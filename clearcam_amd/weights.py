@@ -296,3 +296,50 @@ def synthetic_adaface_state_dict(seed: int = 777) -> Dict[str, np.ndarray]:
     sd["linear.bias"] = (0.01 * rng.standard_normal(512)).astype(np.float32)
     bn(sd, "bn2", 512, affine=False)
     return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# BlazeFace (models/blazeface.py)
+# ----------------------------------------------------------------------------------------------
+BLAZE_BLOCKS = [(24, 24, 1)] * 7 + [(24, 24, 2)] + [(24, 24, 1)] * 7 + [(24, 48, 2)] + [(48, 48, 1)] * 7 + [(48, 96, 2)] + [(96, 96, 1)] * 7
+
+
+def blazeface_anchors() -> np.ndarray:
+    """The 896 MediaPipe BlazeFace anchors (x_center, y_center, w, h) = cell centres of a 16x16 grid (2 per cell) then of an
+    8x8 grid (6 per cell), unit size.  The reference loads them from its checkpoint (models/blazeface.py:124)."""
+    out = []
+    for g, n in ((16, 2), (8, 6)):
+        for y in range(g):
+            for x in range(g):
+                out += [[(x + 0.5) / g, (y + 0.5) / g, 1.0, 1.0]] * n
+    return np.asarray(out, np.float32)
+
+
+def synthetic_blazeface_state_dict(seed: int = 555) -> Dict[str, np.ndarray]:
+    """Seeded BlazeFace state dict with the reference's parameter names.  The score head is biased so that a few dozen of
+    the 896 anchors clear the 0.85 threshold and the overlap rule gets real work."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    def conv(sd, name, co, ci, k, groups=1, gain=1.0, bias=0.05):
+        w = rng.standard_normal((co, ci // groups, k, k), dtype=np.float32)
+        sd[name + ".weight"] = (w * np.float32(gain * math.sqrt(2.0 / (ci // groups * k * k)))).astype(np.float32)
+        sd[name + ".bias"] = (bias * rng.standard_normal(co)).astype(np.float32)
+
+    sd: Dict[str, np.ndarray] = {}
+    conv(sd, "conv_tiny", 24, 3, 5)
+    for i, (cin, cout, stride) in enumerate(BLAZE_BLOCKS):          # gains chosen so 31 un-normalised ReLU blocks stay O(1)
+        p = f"backbone_tiny.list.{i}."
+        conv(sd, p + "conv0_tiny", cin, cin, 3, groups=cin, gain=0.6)
+        conv(sd, p + "conv1_tiny", cout, cin, 1, gain=0.3)
+    conv(sd, "final.conv0_tiny", 96, 96, 3, groups=96, gain=0.6)
+    conv(sd, "final.conv1_tiny", 96, 96, 1, gain=0.7)
+    for name, co in (("classifier_8_tiny", 2), ("classifier_16_tiny", 6)):
+        conv(sd, name, co, 96, 1)
+        sd[name + ".bias"] = (sd[name + ".bias"] - np.float32(3.0)).astype(np.float32)     # ~3 % of the anchors clear 0.85
+    for name, co in (("regressor_8_tiny", 32), ("regressor_16_tiny", 96)):
+        conv(sd, name, co, 96, 1, gain=6.0)
+        b = sd[name + ".bias"]
+        b[2::16] += 60.0; b[3::16] += 60.0                                                   # box width / height ~0.23 of the image
+        sd[name + ".bias"] = b.astype(np.float32)
+    sd["anchors"] = blazeface_anchors()
+    return sd

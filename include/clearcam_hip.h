@@ -114,6 +114,20 @@ int cc_face_embed(cc_face* h, const void* faces, int B, int img_f32, int faces_o
 void cc_face_destroy(cc_face* h);
 
 /* ---------------------------------------------------------------------------------------------
+ * BlazeFace face detector — stands behind `BlazeFace.__call__(img)` (models/blazeface.py:165-192), called by
+ * `ObjectFinder.img_to_face` (models/objects.py:253-255).  Parameters by the reference's state-dict names
+ * (conv_tiny.*, backbone_tiny.list.<i>.conv{0,1}_tiny.*, final.*, classifier_{8,16}_tiny.*, regressor_{8,16}_tiny.*, anchors).
+ * img: (H,W,3) uint8 or float32, channel order untouched -> out (896,17) float32 rows
+ * [ymin,xmin,ymax,xmax, 6 x (kx,ky), score] in source pixels, score-descending, suppressed rows zeroed before the back-map.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cc_blaze cc_blaze;
+int cc_blaze_create(cc_blaze** h, int dtype, int device);
+int cc_blaze_load(cc_blaze* h, const char* name, const float* data, const int64_t* shape, int ndim);
+int cc_blaze_finalize(cc_blaze* h);
+int cc_blaze_detect(cc_blaze* h, const void* img, int H, int W, int img_f32, int img_on_device, float* out, int out_on_device, void* stream);
+void cc_blaze_destroy(cc_blaze* h);
+
+/* ---------------------------------------------------------------------------------------------
  * OC-SORT tracker (host code, no GPU) — stands behind `OCSort(...)` / `OCSort.update(preds, thresh)`
  * (ocsort_tracker/ocsort.py:164-308), the consumer of the detector output (clearcam.py:239,585).
  * dets: n rows [x1,y1,x2,y2,score,class] float32 exactly as cc_yolo_detect writes them (zero rows allowed).

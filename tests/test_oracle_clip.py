@@ -137,3 +137,26 @@ def test_adaface_oracle_structure():
     assert ea.shape == (1, 512) and abs(np.linalg.norm(ea) - 1) < 1e-5 and float((ea @ eb.T)[0, 0]) < 0.9
     assert np.array_equal(o(a), ea) and tuple(o.features(a).shape) == (1, 512, 7, 7)
     assert np.abs(o(a.astype(np.float32)) - ea).max() < 1e-6               # uint8 and float inputs agree
+
+
+def test_blazeface_oracle_structure():
+    """BlazeFace as models/blazeface.py builds it: 31 blocks, 896 anchors (512 on the 16x16 map, 384 on the 8x8 map), the
+    'a row dies if a LOWER-ranked row overlaps it' rule, zero rows mapped through the back-map like every other row."""
+    import torch
+    from clearcam_amd.weights import BLAZE_BLOCKS, blazeface_anchors, synthetic_blazeface_state_dict
+    from oracle.blazeface_oracle import BLOCKS, BlazeFaceOracle
+    assert BLOCKS == BLAZE_BLOCKS and len(BLOCKS) == 31 and [b[2] for b in BLOCKS].count(2) == 3
+    a = blazeface_anchors()
+    assert a.shape == (896, 4) and np.allclose(a[0], [1 / 32, 1 / 32, 1, 1]) and np.allclose(a[512], [1 / 16, 1 / 16, 1, 1])
+    o = BlazeFaceOracle(synthetic_blazeface_state_dict(555))
+    det = torch.zeros(896, 17)
+    det[0] = torch.tensor([0.10, 0.10, 0.30, 0.30] + [0.0] * 12 + [0.95])      # best score ...
+    det[1] = torch.tensor([0.11, 0.11, 0.31, 0.31] + [0.0] * 12 + [0.90])      # ... overlapped by a lower-ranked row -> dies
+    det[2] = torch.tensor([0.60, 0.60, 0.80, 0.80] + [0.0] * 12 + [0.92])
+    post = o.postprocess(det)
+    assert post[:, 16].tolist()[:4] == [0.0, pytest.approx(0.92), pytest.approx(0.90), 0.0]      # sorted by score, first row zeroed
+    img = np.random.default_rng(1).integers(0, 256, (360, 480, 3), dtype=np.uint8)
+    out = o(img)
+    scale, pad_top = min(256 / 480, 256 / 360), (256 - int(360 * min(256 / 480, 256 / 360))) // 2
+    dead = out[out[:, 16] == 0]
+    assert out.shape == (896, 17) and len(dead) > 800 and np.allclose(dead[:, 0], -pad_top / scale) and (out[:, 16] != 0).sum() > 10
