@@ -263,6 +263,35 @@ def main() -> None:
         elapsed = float(t.item())
     n_det = int((out[..., 4] > 0).sum().item())
 
+    streams_multi = None
+    if world > 1 and not args.no_streams:
+        # BASELINE.json configs[3] on the whole node: every rank drives its own cameras (one camera -> one GPU, no collective
+        # in the data path); the job-wide rate is the sum over ranks, the slowest camera anywhere bounds the per-stream FPS.
+        # Local work is exception-safe and the only collective (one all-reduce) is reached by every rank whatever happened.
+        stats = torch.zeros(2, 4, dtype=torch.float64)          # per config: frames/s, fps per camera, H2D GB/s, ok flag
+        err = ""
+        for ci, n_cams in enumerate((8, 64)):
+            try:
+                from clearcam_amd.streams import StreamPipeline, make_cameras
+                from clearcam_amd.weights import shift_class_bias
+                m2 = YOLOv9(args.size, args.res, state_dict=shift_class_bias(sd, -20.0), dtype=args.dtype, device=local)
+                pipe = StreamPipeline(m2, n_cams, n_threads=max(1, min(32, (os.cpu_count() or 8) // world)))
+                cams = make_cameras(n_cams, seed=100 + rank)
+                st = pipe.run(cams, 60 if n_cams == 8 else 24)
+                stats[ci] = torch.tensor([st["frames_per_sec"], st["fps_per_camera"], st["h2d_GBps"], 1.0], dtype=torch.float64)
+                pipe.close(); m2.close(); del cams
+            except Exception as exc:             # noqa: BLE001
+                err = f"{type(exc).__name__}: {exc}"
+        tot = stats.to(dev); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        neg = (-stats[:, 1]).to(dev); dist.all_reduce(neg, op=dist.ReduceOp.MAX)      # min over ranks of fps per camera
+        streams_multi = {}
+        for ci, n_cams in enumerate((8, 64)):
+            streams_multi[f"cams{n_cams}_per_gpu"] = {"cameras_total": n_cams * world, "ranks_ok": int(tot[ci, 3].item()),
+                                                      "frames_per_sec_total": round(float(tot[ci, 0]), 1),
+                                                      "min_fps_per_camera": round(-float(neg[ci]), 2),
+                                                      "h2d_GBps_total": round(float(tot[ci, 2]), 1)}
+        if err:
+            streams_multi["error_rank0"] = err
     sharded = None
     if (world > 1 or os.environ.get("CLEARCAM_BENCH_FORCE_SHARDED")) and not args.no_clip:
         model_was = model
@@ -311,6 +340,8 @@ def main() -> None:
             line["streams"] = stream_side_metrics(local, args.size, args.res, args.dtype)
         if not args.no_clip:
             line["clip"] = clip_side_metrics(local, dev)
+        if streams_multi is not None:
+            line["streams_multi_gpu"] = streams_multi
         if sharded is not None:
             line["search_sharded"] = sharded
         if not args.no_cpu_baseline and world == 1:
