@@ -1,0 +1,29 @@
+# dev tool: soak test - many iterations of every entry point, device memory must not drift
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from clearcam_amd.arch import CLIP_TINY
+from clearcam_amd.weights import shift_class_bias, synthetic_clip_state_dict, synthetic_yolov9_state_dict, synthetic_adaface_state_dict, synthetic_blazeface_state_dict
+from clearcam_amd.yolov9 import YOLOv9
+from clearcam_amd.objects import OpenCLIP, EmbeddingIndex, preprocess_crops
+from clearcam_amd.streams import StreamPipeline, make_cameras
+from clearcam_amd.adaface import ADAFACE
+from clearcam_amd.blazeface import BlazeFace
+def free(): torch.cuda.synchronize(); return torch.cuda.mem_get_info()[0] / 1e6
+rng = np.random.default_rng(0)
+m = YOLOv9("t", 640, state_dict=shift_class_bias(synthetic_yolov9_state_dict("t", 1234), -20.0), dtype="bf16")
+pipe = StreamPipeline(m, 16, (540, 960)); cams = make_cameras(16, 540, 960)
+clip = OpenCLIP(state_dict=synthetic_clip_state_dict(CLIP_TINY, 4321), arch=CLIP_TINY, dtype="bf16")
+ix = EmbeddingIndex(64, 200000)
+face = ADAFACE(state_dict=synthetic_adaface_state_dict(), dtype="bf16"); blaze = BlazeFace(state_dict=synthetic_blazeface_state_dict(), dtype="bf16")
+crops = [rng.integers(0, 256, (int(rng.integers(40, 200)), int(rng.integers(40, 200)), 3), dtype=np.uint8) for _ in range(64)]
+frame = rng.integers(0, 256, (540, 960, 3), dtype=np.uint8); f112 = rng.integers(0, 256, (112, 112, 3), dtype=np.uint8)
+def one_round(n):
+    pipe.run(cams, n, warmup=1)
+    for _ in range(n):
+        x = preprocess_crops(crops, CLIP_TINY.image_size); e = clip.precompute_embedding(x.cpu().numpy()).numpy()
+        if len(ix) + len(e) <= 200000: ix.add(e)
+        ix.search(e[:8], 10); m(frame); face(f112); blaze(frame)
+one_round(5); base = free(); t0 = time.time()
+for r in range(6):
+    one_round(40); print(f"round {r}: free {free():.0f} MB (drift {base - free():+.1f} MB), index rows {len(ix)}", flush=True)
+print("seconds", round(time.time() - t0, 1), "final drift MB", round(base - free(), 1))
