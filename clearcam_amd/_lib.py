@@ -13,7 +13,7 @@ SYMBOLS = [
     "cc_yolo_create", "cc_yolo_load", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_get_tensor",
     "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_destroy", "cc_conv2d_nhwc",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
-    "cc_clip_last_gpu_ms", "cc_clip_destroy", "cc_crop_preprocess",
+    "cc_clip_last_gpu_ms", "cc_clip_destroy", "cc_crop_preprocess", "cc_cv_resize_linear_u8", "cc_cv_warp_affine_u8",
     "cc_blaze_create", "cc_blaze_load", "cc_blaze_finalize", "cc_blaze_detect", "cc_blaze_destroy",
     "cc_face_create", "cc_face_load", "cc_face_finalize", "cc_face_embed", "cc_face_destroy",
     "cc_ocsort_create", "cc_ocsort_update", "cc_ocsort_update_many", "cc_ocsort_num_tracks", "cc_ocsort_destroy",
@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
         "cc_clip_encode_text": [vp, vp, C.c_int, vp, C.c_int, vp],
         "cc_clip_last_gpu_ms": [vp, fp],
         "cc_crop_preprocess": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
+        "cc_cv_resize_linear_u8": [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int],
+        "cc_cv_warp_affine_u8": [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int],
         "cc_blaze_create": [C.POINTER(vp), C.c_int, C.c_int],
         "cc_blaze_load": [vp, C.c_char_p, vp, i64p, C.c_int],
         "cc_blaze_finalize": [vp],

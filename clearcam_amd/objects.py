@@ -212,8 +212,7 @@ class ObjectFinder:
     # -- face models (:213-222): BlazeFace detector + AdaFace embedder on the same engine ------------------------
     def init_face(self, blazeface_kwargs: Optional[dict] = None, adaface_kwargs: Optional[dict] = None):
         """:213-217.  `self.blazeface(Tensor(img)).numpy()` -> (896,17) and `self.adaface(Tensor(face112)).numpy()` -> (1,512)
-        are the reference's two face call surfaces (objects.py:254, clearcam.py:674,1236).  The OpenCV similarity-warp
-        between them (`img_to_face`, objects.py:243-354) is host glue that is not mirrored yet."""
+        are the reference's two face call surfaces (objects.py:254, clearcam.py:674,1236); `img_to_face` joins them."""
         if getattr(self, "face", False):
             return
         from .adaface import ADAFACE
@@ -230,6 +229,64 @@ class ObjectFinder:
                 m.close()
             setattr(self, name, None)
         self.face = False
+
+    # -- face crop alignment (:243-354) ------------------------------------------------------------------------
+    EYE_LEFT, EYE_RIGHT, FACE_SIZE = (38.0, 51.0), (73.0, 51.0), 112      # where the eyes land in the aligned face
+
+    def img_to_face(self, orig):
+        """RGB crop -> aligned 112x112 face (channel-swapped like the reference's final cvtColor) or None.  Steps as in the
+        reference: letterbox to 640 and run BlazeFace; first surviving detection; reject faces narrower than 50 px; cut a
+        square of twice the face size around the eyes' midpoint; rotate it so the eyes are level; scale and shift so they
+        land on EYE_LEFT / EYE_RIGHT.  The pixel operations are clearcam_amd.cvops (GPU, OpenCV-compatible)."""
+        from . import cvops
+        full = np.ascontiguousarray(orig)
+        h, w = full.shape[:2]
+        scale = 640 / max(h, w)
+        small = cvops.resize_linear(full, (int(w * scale), int(h * scale)))
+        gap_w, gap_h = 640 - small.shape[1], 640 - small.shape[0]
+        top, left = gap_h // 2, gap_w // 2
+        boxed = cvops.copy_make_border(small, top, gap_h - top, left, gap_w - left)
+        found = self.blazeface(Tensor(boxed)).numpy()
+        found = found[found[:, 0] != 0]
+        if found.shape[0] == 0:
+            return None
+        first = found[0]
+        offset = np.array([left, top])
+        y1, x1, y2, x2 = ((float(first[0]) - top) / scale, (float(first[1]) - left) / scale,
+                          (float(first[2]) - top) / scale, (float(first[3]) - left) / scale)
+        eye_a = (np.array([first[4], first[5]]) - offset) / scale
+        eye_b = (np.array([first[6], first[7]]) - offset) / scale
+        if (x2 - x1) < 50:
+            return None
+        goal_a, goal_b = np.array(self.EYE_LEFT), np.array(self.EYE_RIGHT)
+        mid = (eye_a + eye_b) / 2
+        tilt = np.degrees(np.arctan2(eye_b[1] - eye_a[1], eye_b[0] - eye_a[0]))
+        side = max(x2 - x1, y2 - y1) * 2.0
+        H, W = full.shape[:2]
+        cx1, cy1 = max(0, int(mid[0] - side / 2)), max(0, int(mid[1] - side / 2))
+        cx2, cy2 = min(W, int(mid[0] + side / 2)), min(H, int(mid[1] + side / 2))
+        if cx2 <= cx1 or cy2 <= cy1:
+            return None
+        cut = full[cy1:cy2, cx1:cx2]
+        ch, cw = cut.shape[:2]
+        corner = np.array([cx1, cy1])
+        rot = cvops.rotation_matrix_2d((cw / 2, ch / 2), float(tilt), 1.0)
+        c, s_ = abs(rot[0, 0]), abs(rot[0, 1])
+        out_w, out_h = int(ch * s_ + cw * c), int(ch * c + cw * s_)
+        rot[0, 2] += out_w / 2 - cw / 2
+        rot[1, 2] += out_h / 2 - ch / 2
+        level = cvops.warp_affine(cut, rot, (out_w, out_h))
+        a_rot = rot[:, :2] @ (eye_a - corner) + rot[:, 2]
+        b_rot = rot[:, :2] @ (eye_b - corner) + rot[:, 2]
+        zoom = np.linalg.norm(goal_b - goal_a) / np.linalg.norm(b_rot - a_rot)
+        place = np.array([[zoom, 0, goal_a[0] - a_rot[0] * zoom], [0, zoom, goal_a[1] - a_rot[1] * zoom]], np.float32)
+        face = cvops.warp_affine(level, place, (self.FACE_SIZE, self.FACE_SIZE))
+        return np.ascontiguousarray(face[:, :, ::-1])
+
+    def preprocess_face(self, img):
+        """:232-241 for an already decoded RGB array: a 112x112x3 image is taken as is, anything else is aligned."""
+        img = np.asarray(img)
+        return img if img.shape == (112, 112, 3) else self.img_to_face(img)
 
     def preprocess(self, img):
         """:237-242 — cv2.resize(img,(224,224),INTER_CUBIC) -> f32/255 -> (x-0.5)/0.5 -> CHW, on the GPU

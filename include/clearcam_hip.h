@@ -113,6 +113,12 @@ int cc_face_finalize(cc_face* h);
 int cc_face_embed(cc_face* h, const void* faces, int B, int img_f32, int faces_on_device, float* out, int out_on_device, void* stream);
 void cc_face_destroy(cc_face* h);
 
+/* The two OpenCV calls of `ObjectFinder.img_to_face` (models/objects.py:247,318,332) for uint8 HWC 3-channel host images:
+ * cv2.resize(src, (dw,dh)) with the default INTER_LINEAR, and cv2.warpAffine(src, M, (dw,dh)) with the defaults
+ * INTER_LINEAR / BORDER_CONSTANT 0 (M = the forward 2x3 matrix, row-major doubles, exactly what cv2 is given). */
+int cc_cv_resize_linear_u8(const uint8_t* src, int H, int W, uint8_t* dst, int dh, int dw, int device);
+int cc_cv_warp_affine_u8(const uint8_t* src, int H, int W, const double* M, uint8_t* dst, int dh, int dw, int device);
+
 /* ---------------------------------------------------------------------------------------------
  * BlazeFace face detector — stands behind `BlazeFace.__call__(img)` (models/blazeface.py:165-192), called by
  * `ObjectFinder.img_to_face` (models/objects.py:253-255).  Parameters by the reference's state-dict names

@@ -160,3 +160,24 @@ def test_blazeface_oracle_structure():
     scale, pad_top = min(256 / 480, 256 / 360), (256 - int(360 * min(256 / 480, 256 / 360))) // 2
     dead = out[out[:, 16] == 0]
     assert out.shape == (896, 17) and len(dead) > 800 and np.allclose(dead[:, 0], -pad_top / scale) and (out[:, 16] != 0).sum() > 10
+
+
+def test_cv_warp_oracle_properties():
+    """oracle/cv_warp_oracle.py: identity / integer shifts are exact, the border is constant 0, the linear resize agrees with an
+    independent float bilinear (torch) to 1 LSB and with a hand 2x2 average on exact decimation."""
+    import torch
+    from oracle import cv_warp_oracle as cvo
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (90, 140, 3), dtype=np.uint8)
+    eye = np.array([[1, 0, 0], [0, 1, 0]], float)
+    assert np.array_equal(cvo.warp_affine_u8(img, eye, (140, 90)), img)
+    sh = cvo.warp_affine_u8(img, np.array([[1, 0, 5], [0, 1, -3]], float), (140, 90))
+    assert np.array_equal(sh[:87, 5:], img[3:, :135]) and not sh[88:].any() and not sh[:, :4].any()
+    r = cvo.resize_linear_u8(img, (300, 200))
+    t = torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None]
+    f = torch.nn.functional.interpolate(t, size=(200, 300), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(np.rint(f) - r).max() <= 1
+    half = cvo.resize_linear_u8(img, (70, 45)).astype(int)
+    assert np.array_equal(half, (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2)
+    R = cvo.get_rotation_matrix_2d((70, 45), 90.0, 1.0)
+    assert np.allclose(R, [[0, 1, 25], [-1, 0, 115]], atol=1e-9)
