@@ -110,6 +110,28 @@ def clip_side_metrics(device_index: int, dev) -> dict:
     out["vit_b32_seconds_per_10k_crops"] = round(10000 / (Bb / dtb), 3)
     mb.close()
     del xb, eb
+    # face path: AdaFace IR-50 embeddings and BlazeFace detections, seeded weights
+    from clearcam_amd.adaface import ADAFACE
+    from clearcam_amd.blazeface import BlazeFace
+    from clearcam_amd.weights import synthetic_adaface_state_dict, synthetic_blazeface_state_dict
+    fa = ADAFACE(state_dict=synthetic_adaface_state_dict(777), dtype="bf16", device=device_index)
+    faces = np.random.default_rng(5).integers(0, 256, (256, 112, 112, 3), dtype=np.uint8)
+    for _ in range(2):
+        fa.embed_batch(faces)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fa.embed_batch(faces)
+    out["adaface_faces_per_sec"] = round(3 * 256 / (time.perf_counter() - t0), 1)       # host in, host out (PCIe included)
+    fa.close()
+    bz = BlazeFace(state_dict=synthetic_blazeface_state_dict(555), dtype="bf16", device=device_index)
+    img = np.random.default_rng(6).integers(0, 256, (640, 640, 3), dtype=np.uint8)
+    for _ in range(3):
+        bz(img)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        bz(img)
+    out["blazeface_ms_per_image"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)     # batch 1, as the reference calls it
+    bz.close()
     # search: 125k x 768 f32 shard (1 M vectors over 8 GPUs), k=100, 1 query; HBM-bound scan of 384 MB
     N = 125_000
     ix = EmbeddingIndex(768, N, device=device_index)
