@@ -24,8 +24,7 @@ def find_vocab(bpe_path: Optional[str] = None) -> str:
     here = os.path.dirname(os.path.abspath(__file__))
     cands = [bpe_path, os.environ.get("CLEARCAM_BPE_VOCAB"),
              os.path.join(here, "assets", "bpe_simple_vocab_16e6.txt.gz"),
-             os.path.join(os.getcwd(), "utils", "bpe_simple_vocab_16e6.txt.gz"),      # inside a clearcam checkout
-             "/root/reference/utils/bpe_simple_vocab_16e6.txt.gz"]
+             os.path.join(os.getcwd(), "utils", "bpe_simple_vocab_16e6.txt.gz")]      # inside a clearcam checkout
     for c in cands:
         if c and os.path.exists(c):
             return c

@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+# the BPE vocabulary is clearcam's own data file; in the build container the reference checkout has it (test infrastructure only)
+_REF_VOCAB = "/root/reference/utils/bpe_simple_vocab_16e6.txt.gz"
+if os.path.exists(_REF_VOCAB):
+    os.environ.setdefault("CLEARCAM_BPE_VOCAB", _REF_VOCAB)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
