@@ -57,3 +57,22 @@ def test_img_to_face_matches_oracle_steps():
     assert done >= 1
     f.turn_off_face()
     assert f.blazeface is None and f.adaface is None
+
+
+def test_face_path_against_committed_golden():
+    """The HIP face path against tests/golden/face_path.npz (oracle outputs committed by tools/make_golden.py)."""
+    import os
+    from clearcam_amd import cvops
+    from clearcam_amd.adaface import ADAFACE
+    from clearcam_amd.blazeface import BlazeFace
+    from clearcam_amd.objects import preprocess_crops
+    from clearcam_amd.weights import synthetic_adaface_state_dict, synthetic_blazeface_state_dict
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "face_path.npz"))
+    assert np.abs(ADAFACE(state_dict=synthetic_adaface_state_dict(777), dtype="f32")(g["face"]).numpy() - g["adaface"]).max() < 3e-5
+    b = BlazeFace(state_dict=synthetic_blazeface_state_dict(555), dtype="f32")(g["img"]).numpy()
+    assert np.array_equal(b[:, 16] != 0, g["blazeface"][:, 16] != 0) and np.abs(b - g["blazeface"]).max() < 2e-2
+    assert np.array_equal(cvops.resize_linear(g["crop"], (200, 90)), g["crop_linear_200x90"])
+    assert np.array_equal(cvops.warp_affine(g["crop"], g["warp_M"], (150, 80)), g["crop_warp_150x80"])
+    cubic = preprocess_crops([g["crop"]]).cpu().numpy()[0]
+    ref = np.transpose((g["crop_cubic_224"].astype(np.float32) / 255.0 - 0.5) / 0.5, (2, 0, 1))
+    assert np.array_equal(cubic, ref.astype(np.float32))

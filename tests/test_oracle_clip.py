@@ -181,3 +181,19 @@ def test_cv_warp_oracle_properties():
     assert np.array_equal(half, (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2)
     R = cvo.get_rotation_matrix_2d((70, 45), 90.0, 1.0)
     assert np.allclose(R, [[0, 1, 25], [-1, 0, 115]], atol=1e-9)
+
+
+def test_face_path_oracles_reproduce_golden():
+    """tests/golden/face_path.npz (tools/make_golden.py) pins the face-path oracles against drift: AdaFace, BlazeFace and the
+    OpenCV restatements must reproduce their committed outputs on this machine."""
+    from clearcam_amd.weights import synthetic_adaface_state_dict, synthetic_blazeface_state_dict
+    from oracle import cv_resize_oracle, cv_warp_oracle
+    from oracle.adaface_oracle import AdaFaceOracle
+    from oracle.blazeface_oracle import BlazeFaceOracle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "face_path.npz"))
+    assert np.abs(AdaFaceOracle(synthetic_adaface_state_dict(777))(g["face"]) - g["adaface"]).max() < 1e-5
+    b = BlazeFaceOracle(synthetic_blazeface_state_dict(555))(g["img"])
+    assert np.array_equal(b[:, 16] != 0, g["blazeface"][:, 16] != 0) and np.abs(b - g["blazeface"]).max() < 2e-2
+    assert np.array_equal(cv_resize_oracle.resize_cubic_u8(g["crop"], 224), g["crop_cubic_224"])
+    assert np.array_equal(cv_warp_oracle.resize_linear_u8(g["crop"], (200, 90)), g["crop_linear_200x90"])
+    assert np.array_equal(cv_warp_oracle.warp_affine_u8(g["crop"], g["warp_M"], (150, 80)), g["crop_warp_150x80"])

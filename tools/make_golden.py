@@ -43,9 +43,32 @@ def letterbox_case():
     print("letterbox", lb.shape)
 
 
+def face_cases():
+    """Face path: AdaFace embedding, BlazeFace detections, OpenCV-compatible resize / warp, cubic crop preprocessing."""
+    from clearcam_amd.weights import synthetic_adaface_state_dict, synthetic_blazeface_state_dict
+    from oracle.adaface_oracle import AdaFaceOracle
+    from oracle.blazeface_oracle import BlazeFaceOracle
+    from oracle import cv_resize_oracle, cv_warp_oracle
+    rng = np.random.default_rng(21)
+    face = rng.integers(0, 256, (112, 112, 3), dtype=np.uint8)
+    img = rng.integers(0, 256, (360, 480, 3), dtype=np.uint8)
+    crop = rng.integers(0, 256, (57, 131, 3), dtype=np.uint8)
+    M = cv_warp_oracle.get_rotation_matrix_2d((65.5, 28.0), 17.5, 1.3)
+    np.savez_compressed(os.path.join(OUT, "face_path.npz"),
+                        face=face, adaface=AdaFaceOracle(synthetic_adaface_state_dict(777))(face),
+                        img=img, blazeface=BlazeFaceOracle(synthetic_blazeface_state_dict(555))(img),
+                        crop=crop, crop_cubic_224=cv_resize_oracle.resize_cubic_u8(crop, 224),
+                        crop_linear_200x90=cv_warp_oracle.resize_linear_u8(crop, (200, 90)),
+                        warp_M=M, crop_warp_150x80=cv_warp_oracle.warp_affine_u8(crop, M, (150, 80)))
+    print("face_path fixtures written")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--face-only" in sys.argv:
+        face_cases(); sys.exit(0)
     yolo_case("yolo_t_640", "t", 640, 1, (2, 640, 640, 3))
     yolo_case("yolo_t_640_from_540x960", "t", 640, 6, (1, 540, 960, 3))
     yolo_case("yolo_c_640", "c", 640, 1, (1, 640, 640, 3))
     letterbox_case()
+    face_cases()
