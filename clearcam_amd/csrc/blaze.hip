@@ -130,7 +130,7 @@ struct cc_blaze {
   bool finalized = false;
   PConv stem; std::vector<BBlock> blocks; PConv fdw, fpw, cls8, cls16, reg8, reg16;
   float* anchors = nullptr;
-  std::map<std::vector<int>, std::unique_ptr<BPlan>> plans;
+  PlanCache<std::vector<int>, BPlan> plans;
 };
 
 namespace {
@@ -163,8 +163,7 @@ template <class T> T* to_dev(BPlan* P, const std::vector<T>& v) {
 
 BPlan* get_plan(cc_blaze* h, int H, int W, int f32) {
   const std::vector<int> key{H, W, f32};
-  auto it = h->plans.find(key);
-  if (it != h->plans.end()) return it->second.get();
+  if (BPlan* hit = h->plans.find(key)) return hit;
   std::unique_ptr<BPlan> P(new BPlan()); P->H = H; P->W = W; P->f32 = f32;
   const size_t es = dtype_size(h->dtype);
   auto act = [&](int hh, int ww, int c, bool zero = false) { return P->alloc((size_t)hh * ww * c * es, zero); };
@@ -225,8 +224,7 @@ BPlan* get_plan(cc_blaze* h, int H, int W, int f32) {
   { BOp op{}; op.kind = 3; op.post = PostP{r8, r16, c8, c16, h->anchors, scale, pad_top, pad_left, (float*)P->alloc((size_t)kAnchors * 17 * 4), P->out_dev}; P->ops.push_back(op); }
   BPlan* pp = P.get();
   P->exec = capture_graph(h->stream, [&]() { run_ops(h, pp, h->stream); });
-  h->plans[key] = std::move(P);
-  return pp;
+  return h->plans.insert(key, std::move(P), h->stream);
 }
 
 }  // namespace

@@ -54,7 +54,7 @@ struct cc_clip {
   // text tower
   float *tok_emb = nullptr, *tpos = nullptr; Norm ln_final; Lin tproj;
   std::vector<Block> tblocks;
-  std::map<int, std::unique_ptr<CPlan>> img_plans, txt_plans;
+  PlanCache<int, CPlan> img_plans, txt_plans;
   bool timed = false;
 };
 
@@ -161,8 +161,7 @@ void capture(cc_clip* h, CPlan* P) {
 }
 
 CPlan* image_plan(cc_clip* h, int B) {
-  auto it = h->img_plans.find(B);
-  if (it != h->img_plans.end()) return it->second.get();
+  if (CPlan* hit = h->img_plans.find(B)) return hit;
   const cc_clip_config& c = h->cfg;
   std::unique_ptr<CPlan> P(new CPlan()); P->B = B;
   const int g = c.image_size / c.patch, L = g * g + 1, D = c.v_width; const size_t es = dtype_size(h->dtype);
@@ -180,12 +179,11 @@ CPlan* image_plan(cc_clip* h, int B) {
   gemm(P.get(), pooled, B, h->proj, P->out_dev, 1, 0, nullptr);
   COp nm{}; nm.kind = 6; nm.nm = NormP{P->out_dev, B, c.embed, 1e-8f}; P->ops.push_back(nm);
   capture(h, P.get());
-  CPlan* raw = P.get(); h->img_plans[B] = std::move(P); return raw;
+  return h->img_plans.insert(B, std::move(P), h->stream);
 }
 
 CPlan* text_plan(cc_clip* h, int B) {
-  auto it = h->txt_plans.find(B);
-  if (it != h->txt_plans.end()) return it->second.get();
+  if (CPlan* hit = h->txt_plans.find(B)) return hit;
   const cc_clip_config& c = h->cfg;
   std::unique_ptr<CPlan> P(new CPlan()); P->B = B;
   const int L = c.t_ctx, D = c.t_width; const size_t es = dtype_size(h->dtype);
@@ -201,7 +199,7 @@ CPlan* text_plan(cc_clip* h, int B) {
   gemm(P.get(), pooled, B, h->tproj, P->out_dev, 1, 0, nullptr);
   COp nm{}; nm.kind = 6; nm.nm = NormP{P->out_dev, B, c.embed, 0.f}; P->ops.push_back(nm);
   capture(h, P.get());
-  CPlan* raw = P.get(); h->txt_plans[B] = std::move(P); return raw;
+  return h->txt_plans.insert(B, std::move(P), h->stream);
 }
 
 }  // namespace

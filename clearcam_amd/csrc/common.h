@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <map>
+#include <memory>
+#include <cstdlib>
 #include <string>
 #include <stdexcept>
 
@@ -105,6 +108,44 @@ struct ConvP {
   int act;                       // 0 none, 1 SiLU, 2 tanh-GELU, 3 PReLU (x > 0 ? x : slope[channel] * x), 4 ReLU applied AFTER the residual add
   const float* slope;            // [Cout] PReLU slopes (act 3), else null
   int variant;                   // kernel choice: 0 auto; tests force 1 direct, 2 generic MFMA, 3 halo-resident 3x3, 4 weights-stationary 3x3, 5 256x256 tiles
+};
+
+// Plan cache of a model handle: one plan (buffers + captured hipGraph) per input shape, bounded.  A service that sees many
+// batch sizes would otherwise keep a multi-GB arena for each of them forever.  At most cap() plans live at once
+// (CLEARCAM_MAX_PLANS, default 16); inserting into a full cache drains the handle's stream and drops the least recently
+// used plan.  `on_evict` lets the owner forget raw pointers to it.
+template <class Key, class PlanT>
+struct PlanCache {
+  struct Slot { std::unique_ptr<PlanT> plan; unsigned long long used; };
+  std::map<Key, Slot> slots;
+  unsigned long long tick = 0;
+  static size_t cap() {
+    static size_t c = 0;
+    if (!c) { const char* e = getenv("CLEARCAM_MAX_PLANS"); const long v = e ? atol(e) : 16; c = (size_t)(v < 1 ? 1 : v); }
+    return c;
+  }
+  PlanT* find(const Key& k) {
+    auto it = slots.find(k);
+    if (it == slots.end()) return nullptr;
+    it->second.used = ++tick;
+    return it->second.plan.get();
+  }
+  template <class OnEvict>
+  PlanT* insert(const Key& k, std::unique_ptr<PlanT> p, hipStream_t stream, OnEvict on_evict) {
+    while (slots.size() >= cap()) {
+      auto victim = slots.begin();
+      for (auto it = slots.begin(); it != slots.end(); ++it) if (it->second.used < victim->second.used) victim = it;
+      CC_HIP(hipStreamSynchronize(stream));              // its graph may still be running
+      on_evict(victim->second.plan.get());
+      slots.erase(victim);
+    }
+    PlanT* raw = p.get();
+    slots[k] = Slot{std::move(p), ++tick};
+    return raw;
+  }
+  PlanT* insert(const Key& k, std::unique_ptr<PlanT> p, hipStream_t stream) { return insert(k, std::move(p), stream, [](PlanT*) {}); }
+  void clear() { slots.clear(); }
+  size_t size() const { return slots.size(); }
 };
 
 }  // namespace cc

@@ -85,7 +85,7 @@ struct cc_face {
   std::vector<void*> wallocs;
   bool finalized = false;
   PConv conv0; std::vector<FBlock> blocks; Affine bn_final; PConv linear;
-  std::map<int, std::unique_ptr<FPlan>> plans;
+  PlanCache<int, FPlan> plans;
 };
 
 namespace {
@@ -148,8 +148,7 @@ void run_ops(cc_face* h, FPlan* P, hipStream_t s) {
 
 FPlan* get_plan(cc_face* h, int B, int img_f32) {
   const int key = B * 2 + img_f32;
-  auto it = h->plans.find(key);
-  if (it != h->plans.end()) return it->second.get();
+  if (FPlan* hit = h->plans.find(key)) return hit;
   std::unique_ptr<FPlan> P(new FPlan()); P->B = B;
   const size_t es = dtype_size(h->dtype);
   auto act_buf = [&](int H, int W, int C) { return P->alloc((size_t)B * H * W * C * es); };
@@ -196,9 +195,7 @@ FPlan* get_plan(cc_face* h, int B, int img_f32) {
   { FOp op{}; op.kind = 4; op.nm = NormP{P->out_dev, B, 512, 0.0f}; P->ops.push_back(op); }
   FPlan* pp = P.get();
   P->exec = capture_graph(h->stream, [&]() { run_ops(h, pp, h->stream); });
-  FPlan* raw = P.get();
-  h->plans[key] = std::move(P);
-  return raw;
+  return h->plans.insert(key, std::move(P), h->stream);
 }
 
 }  // namespace

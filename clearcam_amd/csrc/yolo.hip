@@ -83,7 +83,7 @@ struct cc_yolo {
   std::map<std::string, PackedConv> packed;
   float* dfl_w = nullptr;
   bool finalized = false;
-  std::map<std::vector<int>, std::unique_ptr<Plan>> plans;
+  PlanCache<std::vector<int>, Plan> plans;
   Plan* last = nullptr;
   int cin_pad() const { return dtype == F32 ? 4 : 8; }
 };
@@ -529,8 +529,7 @@ static void run_ops(cc_yolo* Y, Plan* P, hipStream_t s) {
 
 static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32) {
   const std::vector<int> key{B, H, W, frame_f32};
-  auto it = Y->plans.find(key);
-  if (it != Y->plans.end()) return it->second.get();
+  if (Plan* hit = Y->plans.find(key)) return hit;
   std::unique_ptr<Plan> P(new Plan());
   P->B = B; P->H = H; P->W = W; P->frame_f32 = frame_f32;
   // letterbox geometry, detection/yolov9.py:390-403 (python round = half-to-even)
@@ -557,9 +556,8 @@ static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32) {
   CC_HIP(hipStreamEndCapture(Y->stream, &graph));
   CC_HIP(hipGraphInstantiate(&P->exec, graph, nullptr, nullptr, 0));
   CC_HIP(hipGraphDestroy(graph));
-  Plan* raw = P.get();
-  Y->plans[key] = std::move(P);
-  return raw;
+  // a plan that cc_yolo_get_tensor / cc_yolo_profile still point at must not dangle when it is evicted
+  return Y->plans.insert(key, std::move(P), Y->stream, [&](Plan* gone) { if (Y->last == gone) Y->last = nullptr; });
 }
 
 }  // namespace cc

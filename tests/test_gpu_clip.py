@@ -236,3 +236,41 @@ def test_multi_query_scan_matches_single_query_path():
     assert np.array_equal(idx, order) and np.array_equal(s, np.take_along_axis(many, order, 1))
     odd = EmbeddingIndex(768, 50001); odd.add(E); odd.add(E[:1])             # N % 4 != 0 -> GEMV passes, same answers
     assert np.abs(odd.scores(Q[:8])[:, :50000] - many[:8]).max() < 1e-6
+
+
+def test_plan_cache_is_bounded_lru():
+    """One plan (buffers + hipGraph) per input shape, at most CLEARCAM_MAX_PLANS alive: with a cap of 2, cycling through
+    three batch sizes keeps evicting and rebuilding, results stay right and device memory does not grow."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from clearcam_amd.arch import CLIP_TINY
+from clearcam_amd.weights import synthetic_clip_state_dict, synthetic_yolov9_state_dict
+from clearcam_amd.objects import OpenCLIP
+from clearcam_amd.yolov9 import YOLOv9
+from clearcam_amd._lib import CCError
+m = OpenCLIP(state_dict=synthetic_clip_state_dict(CLIP_TINY, 4321), arch=CLIP_TINY, dtype="f32")
+x = np.random.default_rng(0).random((3, 3, 56, 56), dtype=np.float32) * 2 - 1
+ref = {b: m.precompute_embedding(x[:b]).numpy() for b in (1, 2, 3)}
+torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
+for _ in range(5):
+    for b in (1, 2, 3):
+        assert np.array_equal(m.precompute_embedding(x[:b]).numpy(), ref[b])
+torch.cuda.synchronize(); assert abs(torch.cuda.mem_get_info()[0] - free0) < 64 << 20
+y = YOLOv9("t", 320, state_dict=synthetic_yolov9_state_dict("t", 1234), dtype="f32")
+f = np.random.default_rng(1).integers(0, 256, (1, 160, 320, 3), dtype=np.uint8)
+a = y.detect_batch(f)
+y.detect_batch(np.repeat(f, 2, 0)); y.detect_batch(np.repeat(f, 3, 0))        # two more shapes: the first plan is evicted
+try:
+    y.get_tensor("p3")                                                           # the tap's plan is the last one run: still fine
+except CCError as e:
+    raise SystemExit("unexpected: " + str(e))
+assert np.array_equal(y.detect_batch(f), a)                                     # rebuilt, same answer
+print("OK")
+'''
+    env = dict(os.environ, CLEARCAM_MAX_PLANS="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
