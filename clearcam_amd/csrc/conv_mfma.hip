@@ -415,11 +415,14 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
 //     32 MFMA on F1(t)         | 16 DMA issues for stage t+2 (into the buffer of stage t) | 16 ds_read -> F0(t+1)
 // so the LDS-DMA of a stage is issued a whole step before it is needed and the matrix pipe never waits for a fragment.
 // sched_barrier pins the interleave (the scheduler otherwise hoists all reads to the top and spills).
-template <class T>
-__global__ __launch_bounds__(256) void conv_big_kernel(const ConvP p, const ConvAux a) {
-  constexpr int BM = 256, BN = 256, NT = 256, WM = 2, WN = 2, MI = 8, NJ = 8;
+// TS = tile side: 256 (one block per CU, accumulators in AGPRs) or 128 (64 x 64 per wave, two blocks per CU; same schedule).
+template <class T, int TS>
+__global__ __launch_bounds__(256, (TS == 256 ? 1 : 2)) void conv_big_kernel(const ConvP p, const ConvAux a) {
+  constexpr int BM = TS, BN = TS, NT = 256, WM = 2, WN = 2, MI = BM / WM / 16, NJ = BN / WN / 16;
+  constexpr int NF = MI + NJ, MF = MI * NJ, MPG = MF / NF;   // fragments and MFMAs per 32-wide k-substep, MFMAs per fragment read
   constexpr int E = 8, CPRW = 8, BK = 64, RPP = NT / CPRW, XR = BM / RPP, WR = BN / RPP;
-  constexpr int STAGE = (BM + BN) * CPRW;              // uint4 per stage (64 KB); two stages = the 128 KB epilogue tile
+  constexpr int STAGE = (BM + BN) * CPRW;              // uint4 per stage; two stages hold the epilogue tile
+  static_assert(XR + WR == NF && MF % NF == 0 && NF % 2 == 0, "one DMA piece and MF/NF MFMAs per fragment read");
   static_assert(sizeof(T) == 2, "16-bit storage only");
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const ConvP p, const Conv
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment index q < 8 -> pixel fragment q, else weight fragment q - 8, of k-substep h in `stage`
-  uint4 f0[16], f1[16];
+  uint4 f0[NF], f1[NF];
   auto frag = [&](int stage, int h, int q) -> uint4 {
     const int row = (q < MI ? wm0 + q * 16 : BM + wn0 + (q - MI) * 16) + fr;   // row in the stage: pixels first, then weights
     const int srow = q < MI ? row : row - BM;                                    // swizzle uses the row inside its own slab
@@ -533,26 +536,26 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const ConvP p, const Conv
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) f0[q] = frag(0, 0, q);
+  for (int q = 0; q < NF; ++q) f0[q] = frag(0, 0, q);
 
   // one K step; MORE = a next step exists (barrier + its first fragments), MORE2 = a step after that exists (its DMA).
   // The last two steps are peeled so that the steady-state body has no branches between MFMA groups.
   auto step = [&](int kt, auto more_tag, auto more2_tag) {
     constexpr bool MORE = decltype(more_tag)::value, MORE2 = decltype(more2_tag)::value;
     const int st = kt & 1;
-    // substep 0: 64 MFMAs on F0, the 16 reads of F1 spread underneath
+    // substep 0: the MFMAs on F0, the reads of F1 spread underneath (one read per MPG MFMAs)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < NF; ++g) {
       f1[g] = frag(st, 1, g);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int j = g >> 1, i = (g & 1) * 4 + u; Mma<T>::run(f0[MI + j], f0[i], acc[j][i]); }
+      for (int u = 0; u < MPG; ++u) { const int e = g * MPG + u, j = e / MI, i = e % MI; Mma<T>::run(f0[MI + j], f0[i], acc[j][i]); }
       __builtin_amdgcn_sched_barrier(0);
     }
     // substep 1, first half
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < NF / 2; ++g) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int j = g >> 1, i = (g & 1) * 4 + u; Mma<T>::run(f1[MI + j], f1[i], acc[j][i]); }
+      for (int u = 0; u < MPG; ++u) { const int e = g * MPG + u, j = e / MI, i = e % MI; Mma<T>::run(f1[MI + j], f1[i], acc[j][i]); }
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (MORE) {
@@ -562,11 +565,12 @@ __global__ __launch_bounds__(256) void conv_big_kernel(const ConvP p, const Conv
     }
     // substep 1, second half: DMA of stage kt+2 into the dead buffer and the reads of F0(kt+1) ride under the MFMAs
 #pragma unroll
-    for (int g = 8; g < 16; ++g) {
-      if constexpr (MORE2) { issue_piece(st, 2 * (g - 8)); issue_piece(st, 2 * (g - 8) + 1); }
-      if constexpr (MORE) { f0[2 * (g - 8)] = frag(st ^ 1, 0, 2 * (g - 8)); f0[2 * (g - 8) + 1] = frag(st ^ 1, 0, 2 * (g - 8) + 1); }
+    for (int g = NF / 2; g < NF; ++g) {
+      const int q = 2 * (g - NF / 2);
+      if constexpr (MORE2) { issue_piece(st, q); issue_piece(st, q + 1); }
+      if constexpr (MORE) { f0[q] = frag(st ^ 1, 0, q); f0[q + 1] = frag(st ^ 1, 0, q + 1); }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int j = g >> 1, i = (g & 1) * 4 + u; Mma<T>::run(f1[MI + j], f1[i], acc[j][i]); }
+      for (int u = 0; u < MPG; ++u) { const int e = g * MPG + u, j = e / MI, i = e % MI; Mma<T>::run(f1[MI + j], f1[i], acc[j][i]); }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -853,6 +857,16 @@ static void launch_cfg(const ConvP& p, const ConvAux& a, int M, int bm, int ns, 
   }
 }
 
+template <class T, int TS> static void launch_big(const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * (2 * TS) * 8 * 16;
+  static bool configured = false;
+  if (!configured) {
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<T, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((conv_big_kernel<T, TS>), dim3(((M + TS - 1) / TS) * a.nt), dim3(256), lds, stream, p, a);
+}
+
 template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const ConvAux& a, int bn, int M, hipStream_t stream) {
   if (g_cfg[0] < 0) {
     g_cfg[0] = 128; g_cfg[1] = 2; g_cfg[2] = 128; g_cfg[3] = 2;
@@ -862,20 +876,20 @@ template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const Conv
     if constexpr (SIMPLE && sizeof(T) == 2) {
       static int sched = -1;
       if (sched < 0) { const char* e = getenv("CLEARCAM_BIG_SCHED"); sched = e ? atoi(e) : 1; }
-      if (sched) {
-        constexpr size_t lds = (size_t)2 * 512 * 8 * 16;
-        static bool configured = false;
-        if (!configured) {
-          CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          configured = true;
-        }
-        hipLaunchKernelGGL((conv_big_kernel<T>), dim3(((M + 255) / 256) * a.nt), dim3(256), lds, stream, p, a);
-        return;
-      }
+      if (sched) { launch_big<T, 256>(p, a, M, stream); return; }
     }
     launch_k<T, 256, 256, 4, SIMPLE, 8, 2>(p, a, (M + 255) / 256, stream);
   }
-  else if (bn == 128) launch_cfg<T, 128, SIMPLE>(p, a, M, g_cfg[0], g_cfg[1], stream);
+  else if (bn == 128) {
+    if constexpr (SIMPLE && sizeof(T) == 2) {
+      // the single-barrier, register-double-buffered schedule with 128x128 tiles: 4-5 % faster than the two-barrier loop
+      // for K >= 1024 (3x3 with >= 128 channels, deep 1x1), 3-8 % slower for short K (per-layer A/B, YOLOv9-C B=64)
+      static int mid = -1;
+      if (mid < 0) { const char* e = getenv("CLEARCAM_MID_SCHED"); mid = e ? atoi(e) : 1024; }
+      if ((mid > 0 && p.Ktot >= mid) || p.variant == 6) { launch_big<T, 128>(p, a, M, stream); return; }
+    }
+    launch_cfg<T, 128, SIMPLE>(p, a, M, g_cfg[0], g_cfg[1], stream);
+  }
   else if (bn == 64) launch_cfg<T, 64, SIMPLE>(p, a, M, g_cfg[2], g_cfg[3], stream);
   else launch_k<T, 128, 32, 4, SIMPLE, 8, 2>(p, a, (M + 127) / 128, stream);
 }
@@ -986,6 +1000,7 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
       if ((big > 0 && fits && !p.res && p.variant == 0) || big < 0 || p.variant == 5) bn = 256;
     }
   }
+  if (p.variant == 6) bn = 128;
   ConvAux a{};
   a.nt = (p.Cout + bn - 1) / bn;
   a.inv_hw = 1.0f / (float)(p.Ho * p.Wo); a.inv_wo = 1.0f / (float)p.Wo;
