@@ -242,7 +242,8 @@ class ObjectFinder:
         full = np.ascontiguousarray(orig)
         h, w = full.shape[:2]
         scale = 640 / max(h, w)
-        small = cvops.resize_linear(full, (int(w * scale), int(h * scale)))
+        dev = self.blazeface.device                               # pixel ops on the GPU that runs the face models
+        small = cvops.resize_linear(full, (int(w * scale), int(h * scale)), dev)
         gap_w, gap_h = 640 - small.shape[1], 640 - small.shape[0]
         top, left = gap_h // 2, gap_w // 2
         boxed = cvops.copy_make_border(small, top, gap_h - top, left, gap_w - left)
@@ -275,12 +276,12 @@ class ObjectFinder:
         out_w, out_h = int(ch * s_ + cw * c), int(ch * c + cw * s_)
         rot[0, 2] += out_w / 2 - cw / 2
         rot[1, 2] += out_h / 2 - ch / 2
-        level = cvops.warp_affine(cut, rot, (out_w, out_h))
+        level = cvops.warp_affine(cut, rot, (out_w, out_h), dev)
         a_rot = rot[:, :2] @ (eye_a - corner) + rot[:, 2]
         b_rot = rot[:, :2] @ (eye_b - corner) + rot[:, 2]
         zoom = np.linalg.norm(goal_b - goal_a) / np.linalg.norm(b_rot - a_rot)
         place = np.array([[zoom, 0, goal_a[0] - a_rot[0] * zoom], [0, zoom, goal_a[1] - a_rot[1] * zoom]], np.float32)
-        face = cvops.warp_affine(level, place, (self.FACE_SIZE, self.FACE_SIZE))
+        face = cvops.warp_affine(level, place, (self.FACE_SIZE, self.FACE_SIZE), dev)
         return np.ascontiguousarray(face[:, :, ::-1])
 
     def preprocess_face(self, img):
