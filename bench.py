@@ -327,7 +327,22 @@ def main() -> None:
         model = model_was
     if rank == 0:
         fps = world * B * args.steps / elapsed
+        import csv
+        import tempfile
+        tmp_csv = os.path.join(tempfile.gettempdir(), f"clearcam_per_launch_{os.getpid()}.csv")
+        os.environ["CLEARCAM_PROFILE_CSV"] = tmp_csv      # cc_yolo_profile also writes its per-launch table there
         prof = model.profile(iters=3)
+        os.environ.pop("CLEARCAM_PROFILE_CSV", None)
+        heaviest = None
+        try:
+            rows = [r for r in csv.DictReader(open(tmp_csv)) if r["kind"] == "conv"]
+            top = max(rows, key=lambda r: float(r["ms"]))
+            heaviest = {"layer": f"{top['ks']}x{top['ks']} s{top['stride']} {top['Cin']}->{top['Cout']}, {int(float(top['M']))} output pixels",
+                        "ms": round(float(top["ms"]), 4), "TFLOP/s": float(top["tflops"]), "min_GB/s": float(top["gbs"]),
+                        "frac_of_peak": round(float(top["tflops"]) / PEAK_TFLOPS[args.dtype], 4)}
+            os.remove(tmp_csv)
+        except Exception:                         # noqa: BLE001  the table is a convenience, never fatal
+            pass
         alg_flops = 2.0 * prof["alg_macs_per_step"]
         conv_s = prof["conv_ms"] * 1e-3
         achieved = alg_flops / conv_s / 1e12
@@ -353,7 +368,7 @@ def main() -> None:
                                          if traffic else None,
                          "kernel": "conv kernels: conv_mfma_kernel (all instantiations) + conv_big_kernel + conv3x3_halo_kernel + conv3x3_ws_kernel",
                          "alg_gflop_per_step": round(alg_flops / 1e9, 2), "kernel_ms_per_step": round(prof["conv_ms"], 3),
-                         "launches_per_step": prof["conv_launches"],
+                         "launches_per_step": prof["conv_launches"], "heaviest_launch": heaviest,
                          "other_ms_per_step": {k: round(prof[k], 3) for k in ("pool_ms", "decode_ms", "nms_ms")}},
             "gflop_per_frame": round(alg_flops / B / 1e9, 2),
         }
