@@ -100,7 +100,7 @@ __global__ __launch_bounds__(1024) void blaze_post_kernel(const PostP p) {
     const float x1 = box[i][0], y1 = box[i][1], x2 = box[i][2], y2 = box[i][3];
     const float area = (x2 - x1) * (y2 - y1);
     int hits = 0;
-    for (int j = i + 1; j < kAnchors; ++j) {                     // triu(diagonal=1), summed over axis 1: later (lower-ranked) rows
+    for (int j = 0; j < i; ++j) {                                // triu(diagonal=1) of the (1,N,N) mask summed over axis 1: better-ranked rows j < i (:232-234)
       const float u1 = box[j][0], v1 = box[j][1], u2 = box[j][2], v2 = box[j][3];
       const float w = fmaxf(0.0f, fminf(x2, u2) - fmaxf(x1, u1)), h = fmaxf(0.0f, fminf(y2, v2) - fmaxf(y1, v1));
       const float inter = w * h;

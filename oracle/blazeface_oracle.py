@@ -100,7 +100,9 @@ class BlazeFaceOracle:
         h = torch.clamp(torch.minimum(y2[:, None], y2[None, :]) - torch.maximum(y1[:, None], y1[None, :]), min=0)
         inter = w * h
         iou = torch.triu(inter / (area[:, None] + area[None, :] - inter), diagonal=1)      # NaN (0/0) compares False
-        keep = ((iou > 0.3).sum(1) == 0) & (b[:, 16] >= 0.85)
+        # the reference sums the (1,N,N) mask over axis=1, i.e. over the HIGHER-ranked row index i of triu's (i < j) pairs:
+        # row j is dropped when any better-scored row overlaps it (models/blazeface.py:232-234)
+        keep = ((iou > 0.3).sum(0) == 0) & (b[:, 16] >= 0.85)
         return b * keep.float()[:, None]
 
     @torch.no_grad()

@@ -141,7 +141,8 @@ def test_adaface_oracle_structure():
 
 def test_blazeface_oracle_structure():
     """BlazeFace as models/blazeface.py builds it: 31 blocks, 896 anchors (512 on the 16x16 map, 384 on the 8x8 map), the
-    'a row dies if a LOWER-ranked row overlaps it' rule, zero rows mapped through the back-map like every other row."""
+    'a row dies if a BETTER-ranked row overlaps it' rule (the (1,N,N) triu mask summed over axis 1, models/blazeface.py:232-234;
+    pinned by tests/test_reference_run.py), zero rows mapped through the back-map like every other row."""
     import torch
     from clearcam_amd.weights import BLAZE_BLOCKS, blazeface_anchors, synthetic_blazeface_state_dict
     from oracle.blazeface_oracle import BLOCKS, BlazeFaceOracle
@@ -151,10 +152,10 @@ def test_blazeface_oracle_structure():
     o = BlazeFaceOracle(synthetic_blazeface_state_dict(555))
     det = torch.zeros(896, 17)
     det[0] = torch.tensor([0.10, 0.10, 0.30, 0.30] + [0.0] * 12 + [0.95])      # best score ...
-    det[1] = torch.tensor([0.11, 0.11, 0.31, 0.31] + [0.0] * 12 + [0.90])      # ... overlapped by a lower-ranked row -> dies
+    det[1] = torch.tensor([0.11, 0.11, 0.31, 0.31] + [0.0] * 12 + [0.90])      # ... overlaps this lower-ranked row, which dies
     det[2] = torch.tensor([0.60, 0.60, 0.80, 0.80] + [0.0] * 12 + [0.92])
     post = o.postprocess(det)
-    assert post[:, 16].tolist()[:4] == [0.0, pytest.approx(0.92), pytest.approx(0.90), 0.0]      # sorted by score, first row zeroed
+    assert post[:, 16].tolist()[:4] == [pytest.approx(0.95), pytest.approx(0.92), 0.0, 0.0]      # sorted by score, third row zeroed
     img = np.random.default_rng(1).integers(0, 256, (360, 480, 3), dtype=np.uint8)
     out = o(img)
     scale, pad_top = min(256 / 480, 256 / 360), (256 - int(360 * min(256 / 480, 256 / 360))) // 2

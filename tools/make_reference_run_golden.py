@@ -1,0 +1,118 @@
+"""Run the REFERENCE'S OWN model code here and store what it returns: tests/golden/refrun_*.npz.
+
+The reference's detection/yolov9.py, models/objects.py (OpenCLIP), models/adaface.py and models/blazeface.py are imported
+unchanged from /root/reference.  Their only missing dependency, tinygrad, is replaced by `tools/refshim/tinygrad` (a
+PyTorch-CPU implementation of the Tensor / nn calls those files make; see its docstring for what that does and does not
+pin) and `import cv2` by a placeholder that nothing here touches.  Weights are this repo's seeded synthetic checkpoints,
+loaded through the reference's own constructors (`load_state_dict(self, safe_load(fetch(...)))`, strict), which also checks
+that their key names and shapes are exactly the reference's module tree.
+
+Inputs are regenerated from the seeds stored in each file; tests/test_reference_run.py compares the CPU oracle with these
+outputs, tests/test_gpu_reference_run.py the HIP path.  Needs /root/reference, so it runs in the build container only:
+
+    python tools/make_reference_run_golden.py [yolo] [clip] [adaface] [blazeface]
+"""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("CLEARCAM_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path[:0] = [os.path.join(ROOT, "tools", "refshim"), REF, ROOT]
+os.chdir(REF)                                                       # the reference opens a few files relative to its root
+
+# models/objects.py does `from clearcam import event_img_info`; importing the NVR server module itself is out of the question
+_cl = types.ModuleType("clearcam")
+_cl.event_img_info = lambda *a, **k: None
+sys.modules["clearcam"] = _cl
+
+from tinygrad import Tensor  # noqa: E402  (the stand-in)
+from tinygrad.nn import state  # noqa: E402
+from clearcam_amd.arch import CLIP_L14  # noqa: E402
+from clearcam_amd.weights import (synthetic_adaface_state_dict, synthetic_blazeface_state_dict,  # noqa: E402
+                                  synthetic_clip_state_dict, synthetic_yolov9_state_dict)
+
+torch.set_grad_enabled(False)
+
+# (name, size, res, frame seed, frame shape): every detector size; square, letterboxed-wide and letterboxed-tall frames
+YOLO_CASES = [("t_320", "t", 320, 7, (320, 320, 3)), ("t_640_from_540x960", "t", 640, 8, (540, 960, 3)),
+              ("s_320_from_400x300", "s", 320, 9, (400, 300, 3)), ("m_320", "m", 320, 10, (320, 320, 3)),
+              ("c_640", "c", 640, 11, (640, 640, 3)), ("e_640_from_360x640", "e", 640, 12, (360, 640, 3))]
+CLIP_QUERIES = ["a white van parked on the street", "person walking a dog at night"]
+
+
+def frame_of(seed, shape):
+    return np.random.default_rng(seed).integers(0, 256, shape, dtype=np.uint8)
+
+
+def run_yolo():
+    from detection.yolov9 import YOLOv9
+    for name, size, res, seed, shape in YOLO_CASES:
+        sd = dict(synthetic_yolov9_state_dict(size, 1234))
+        head = 42 if size == "e" else 22
+        # buffers a real checkpoint carries and the constructor's strict load asks for; __call__ recomputes both (:209)
+        sd[f"model.list.{head}.anchors"] = np.zeros((2, 22680), np.float32)
+        sd[f"model.list.{head}.strides"] = np.zeros((1, 22680), np.float32)
+        state.inject(f"yolov9-{size}.safetensors", sd)
+        t = time.time()
+        model = YOLOv9(size, res)
+        assert state.LOADED[-1][1] == [], f"checkpoint keys the reference model does not have: {state.LOADED[-1][1][:5]}"
+        frame = frame_of(seed, shape)
+        det = model(Tensor(frame)).numpy()
+        np.savez_compressed(os.path.join(OUT, f"refrun_yolo_{name}.npz"), size=size, res=res, seed=seed, shape=np.array(shape),
+                            weights_seed=1234, det=det.astype(np.float32))
+        print(f"yolo {name}: {(det[:, 4] > 0).sum()} detections, {time.time() - t:.1f}s")
+
+
+def run_clip():
+    sd = dict(synthetic_clip_state_dict(CLIP_L14, 4321))
+    sd["attn_mask"] = np.triu(np.full((77, 77), -np.inf, np.float32), 1)     # open_clip's buffer, part of the real checkpoint
+    state.inject("CLIP-ViT-L-14-laion2B-s32B-b82K.safetensors", sd)
+    from models.objects import OpenCLIP
+    model = OpenCLIP()
+    assert state.LOADED[-1][1] == []
+    x = np.random.default_rng(5).standard_normal((2, 3, 224, 224)).astype(np.float32)
+    img = model.precompute_embedding(Tensor(x)).numpy()
+    tokens, text = [], []
+    for q in CLIP_QUERIES:
+        ids = [49406] + model.tokenizer.encode(q) + [49407]
+        tokens.append(ids + [0] * (77 - len(ids)))
+        text.append(model._encode_text(q, realize=True))
+    np.savez_compressed(os.path.join(OUT, "refrun_clip_l14.npz"), weights_seed=4321, image_seed=5, image_emb=img.astype(np.float32),
+                        queries=np.array(CLIP_QUERIES), tokens=np.array(tokens, np.int32), text_emb=np.stack(text).astype(np.float32))
+    print("clip: image", img.shape, "text", np.stack(text).shape, "cos(img, text)", float(img[0] @ text[0]))
+
+
+def run_adaface():
+    state.inject("adaface_ir50_ms1mv2.safetensors", synthetic_adaface_state_dict(777))
+    from models.adaface import ADAFACE
+    model = ADAFACE()
+    assert state.LOADED[-1][1] == []
+    faces = np.stack([frame_of(21, (112, 112, 3)), frame_of(22, (112, 112, 3))])
+    emb = np.concatenate([model(Tensor(f)).numpy() for f in faces])
+    np.savez_compressed(os.path.join(OUT, "refrun_adaface.npz"), weights_seed=777, face_seeds=np.array([21, 22]), emb=emb.astype(np.float32))
+    print("adaface:", emb.shape, "norms", np.linalg.norm(emb, axis=1))
+
+
+def run_blazeface():
+    state.inject("blazeface.safetensors", synthetic_blazeface_state_dict(555))
+    from models.blazeface import BlazeFace
+    model = BlazeFace()
+    assert state.LOADED[-1][1] == []
+    out = {}
+    for name, seed, shape in (("wide", 21, (360, 480, 3)), ("tall", 23, (500, 300, 3)), ("square", 24, (256, 256, 3))):
+        det = model(Tensor(frame_of(seed, shape))).numpy()
+        out[f"{name}_seed"], out[f"{name}_shape"], out[f"{name}_det"] = seed, np.array(shape), det.astype(np.float32)
+        print(f"blazeface {name}: {(det[:, 16] != 0).sum()} rows kept")
+    np.savez_compressed(os.path.join(OUT, "refrun_blazeface.npz"), weights_seed=555, **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["yolo", "clip", "adaface", "blazeface"]
+    for w in which:
+        {"yolo": run_yolo, "clip": run_clip, "adaface": run_adaface, "blazeface": run_blazeface}[w]()
