@@ -1,8 +1,10 @@
 """CPU oracle for the AdaFace IR-50 face embedder, `ADAFACE.__call__` (models/adaface.py:61-95).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/ (and nothing under clearcam_amd/).  PyTorch-CPU fp32 restatement.
-PARITY UNPINNED: tinygrad (pinned fe39cf14, not vendored) and the adaface_ir50_ms1mv2 checkpoint the reference downloads
-(adaface.py:77) are not available offline and the reference keeps no face-embedding fixture; what is restated here is the
+PIN STATUS: tinygrad (pinned fe39cf14, not vendored) and the adaface_ir50_ms1mv2 checkpoint the reference downloads
+(adaface.py:77) are not available offline and the reference keeps no face-embedding fixture ("parity unpinned" against trained
+weights and tinygrad's kernels).  What pins this file: models/adaface.py itself, executed unchanged over a PyTorch stand-in for
+tinygrad (tools/refshim) on the seeded checkpoint - tests/test_reference_run.py, |diff| <= 5e-6 (measured 2e-7).  Restated: the
 graph as written plus tinygrad's documented inference-mode BatchNorm ((x - running_mean) * rsqrt(running_var + 1e-5) * w + b).
 
 Graph (adaface.py): x (112,112,3) BGR -> [:,:,::-1] -> /255 -> (x-0.5)/0.5 -> CHW -> conv0 3x3 (3->64, no bias) -> bn0 ->

@@ -1,8 +1,11 @@
 """CPU oracle for the BlazeFace face detector, `BlazeFace.__call__(img)` (models/blazeface.py:165-192).
 
 TEST INFRASTRUCTURE ONLY (tests/ import it; nothing under clearcam_amd/ does).  PyTorch-CPU fp32 + numpy restatement.
-PARITY UNPINNED: tinygrad (pinned fe39cf14) is not available offline and models/blazeface.safetensors is a missing large
-blob of the reference checkout; the reference keeps no face-detection fixture.  Restated from the file as written:
+PIN STATUS: tinygrad (pinned fe39cf14) is not available offline and models/blazeface.safetensors is a missing large
+blob of the reference checkout; the reference keeps no face-detection fixture ("parity unpinned" against trained weights and
+tinygrad's kernels).  What pins this file: models/blazeface.py itself, executed unchanged over a PyTorch stand-in for tinygrad
+(tools/refshim) on the seeded checkpoint, three image shapes - tests/test_reference_run.py, identical rows, |diff| 0.0.  (That
+run is what caught an earlier misreading of the overlap rule's axis.)  Restated from the file as written:
   preprocess (:166-179)  scale = min(256/w, 256/h); new = int(w*scale), int(h*scale) (truncation); helpers.resize (tinygrad
                          bilinear, align_corners=False; uint8 input uses tinygrad's 7-bit fixed-point lerp like the detector's
                          letterbox); centred zero pad to 256x256; x/127.5 - 1 (the padding becomes -1); no channel flip
@@ -12,7 +15,7 @@ blob of the reference checkout; the reference keeps no face-detection fixture.  
                          outputs flattened in (H, W, anchor) order: 512 anchors of the 16x16 map then 384 of the 8x8 map
   decode (:204-226)      boxes / keypoints relative to the 896 anchors (scale 256), score = sigmoid(clip(raw, +-100))
   postprocess (:228-238) rows below 0.85 zeroed; sort by score descending (stable); a row survives iff it is >= 0.85 and
-                         overlaps NO LOWER-RANKED row by IoU > 0.3 (triu + sum over axis 1, as written); others zeroed
+                         is overlapped by NO BETTER-RANKED row by IoU > 0.3 (triu of the (1,N,N) mask summed over axis 1); others zeroed
   back-map (:188-192)    * 256; columns 0,2 -= pad_top; columns 1,3 -= pad_left; ALL 17 columns /= scale (as written)
 """
 from __future__ import annotations

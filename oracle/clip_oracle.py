@@ -8,7 +8,11 @@ Restates ``models/objects.py`` of roryclear/clearcam — ``OpenCLIP.precompute_e
 PARITY PINNING: the reference carries two golden 768-d image embeddings
 (``test/clip_images/embeddings.pkl``) and one scalar (``test/test_clip.py:12``: cos = 0.330654), but both
 need the real ViT-L/14 checkpoint (fetched from HuggingFace at construction, :91) and cv2 — neither exists
-offline, so THIS ORACLE IS UNPINNED against the reference's outputs ("parity unpinned").  What is checked:
+offline, so this oracle is unpinned against the TRAINED model's outputs ("parity unpinned" for those three numbers).
+What pins it: the reference's own ``OpenCLIP`` class and ``encode_text`` executed unchanged over a PyTorch stand-in for
+tinygrad (tools/refshim) on the seeded ViT-L/14 checkpoint, and the reference's own ``ObjectFinder.search`` /
+``_load_all_embeddings`` run on pickles in its format (tests/golden/refrun_clip_l14.npz, refrun_search.npz;
+tests/test_reference_run.py: embeddings within 2e-6 (measured 1e-7), search results identical);
 the tokenizer against ids produced by the reference's own tokenizer run in this container
 (tests/golden/tokenizer_kats.json), the golden pickle's self-consistency (unit norm, cos(f40,micra)),
 and structural pins (parameter count, 81.0 GMAC/image).  The reference's pins are restated in

@@ -5,12 +5,20 @@ roryclear/clearcam in PyTorch-CPU float32 + numpy integer arithmetic.  Only ``te
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the
 product path (``clearcam_amd``) never does.
 
-PARITY UNPINNED: the reference stores no detections/boxes anywhere (``test/tracks.pkl`` and
+PIN STATUS: the reference stores no detections/boxes anywhere (``test/tracks.pkl`` and
 ``test/tracker_inputs.pkl`` are missing blobs), tinygrad (pinned ``fe39cf14``, not vendored) cannot
-be imported here, and no weights exist offline — so this restatement cannot be checked against the
-reference's own outputs.  What *is* pinned: parameter count 25.29 M / 51.07 GMAC for size "c"
-(the YOLOv9 paper's figures), the state-dict key set and the integer
-letterbox arithmetic (tests/test_oracle_yolo.py).  tinygrad semantics taken from SURVEY.md
+be imported here and no trained weights exist offline.  What pins this file: the reference's OWN
+``detection/yolov9.py`` + ``utils/helpers.resize`` executed unchanged over a PyTorch stand-in for
+tinygrad (tools/refshim, tools/make_reference_run_golden.py) on seeded checkpoints for all five sizes;
+tests/test_reference_run.py requires row-for-row agreement (same surviving rows and classes, boxes
+<= 0.1 px, scores <= 2e-4; measured 0.04 px / 6e-5 = float32 reassociation).  That fixes the layer
+wiring, concat orders, decode, top-k, NMS and box scaling to the reference's code.  STILL UNPINNED
+("parity unpinned" for these): tinygrad's own kernels, i.e. summation order, the uint8 fixed-point
+``interpolate`` / ``lerp`` and the tie order of ``topk`` (restated in both this file and the stand-in),
+and trained weights.  Also pinned: parameter count 25.29 M / 51.07 GMAC for size "c"
+(the YOLOv9 paper's figures), the state-dict key set (the reference's strict ``load_state_dict``
+accepts the synthetic checkpoints) and the integer letterbox arithmetic (tests/test_oracle_yolo.py).
+tinygrad semantics taken from SURVEY.md
 Appendix B: uint8 ``lerp`` fixed point, zero letterbox padding, ``avg_pool2d`` count_include_pad,
 ``max_pool2d`` -inf padding, stable descending top-k.  One third-party detail cannot be verified
 offline: tinygrad may lower ``x / c`` to ``x * (1/c)``; this restatement divides (<= 1 ulp apart).

@@ -80,3 +80,16 @@ def test_blazeface_hip_equals_reference_run():
         assert np.abs(ref[alive, 16] - got[alive, 16]).max() <= 1e-5 * 256 / scale
         assert np.allclose(ref[~alive], got[~alive], atol=1e-6)
     m.close()
+
+
+def test_search_hip_equals_reference_run():
+    """ObjectFinder.search over the device index == the reference's ObjectFinder.search on the same store (paths, order, scores)."""
+    import json
+    from clearcam_amd.objects import ObjectFinder
+    g = np.load(os.path.join(GOLD, "refrun_search.npz"))
+    f = ObjectFinder()
+    f.image_embeddings = {str(p): e[None] for p, e in zip(g["paths"], g["embs"])}
+    for kw, ref in zip(json.loads(str(g["cases"])), json.loads(str(g["results"]))):
+        got = f.search(text_embedding=g["query"], **kw)
+        assert [p for p, _ in got] == [p for p, _ in ref], kw
+        assert np.allclose([s for _, s in got], [s for _, s in ref], atol=1e-6)

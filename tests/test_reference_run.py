@@ -86,3 +86,22 @@ def test_blazeface_oracle_equals_reference_run():
         assert (ref[:, 16] != 0).sum() >= 30
         assert np.array_equal(ref[:, 16] != 0, got[:, 16] != 0)                 # score test + overlap rule keep the same rows
         assert np.abs(ref - got).max() <= 1e-3                                  # source pixels; measured 0.0
+
+
+def _search_fixture():
+    import json
+    g = np.load(os.path.join(GOLD, "refrun_search.npz"))
+    store = {str(p): e[None] for p, e in zip(g["paths"], g["embs"])}
+    return store, g["query"], json.loads(str(g["cases"])), json.loads(str(g["results"]))
+
+
+def test_search_restatement_equals_reference_run():
+    """The reference's ObjectFinder._load_all_embeddings + search (models/objects.py:356-422, with clearcam.py's own
+    event_img_info) run on pickles in its own format; the restated loop must return the same paths in the same order."""
+    from oracle.clip_oracle import search_reference
+    store, q, cases, results = _search_fixture()
+    assert [len(r) for r in results] == [10, 3, 10, 10, 8, 0]
+    for kw, ref in zip(cases, results):
+        got = search_reference(store, q, **kw)
+        assert [p for p, _ in got] == [p for p, _ in ref], kw
+        assert np.allclose([s for _, s in got], [s for _, s in ref], atol=1e-6)

@@ -10,7 +10,7 @@ that their key names and shapes are exactly the reference's module tree.
 Inputs are regenerated from the seeds stored in each file; tests/test_reference_run.py compares the CPU oracle with these
 outputs, tests/test_gpu_reference_run.py the HIP path.  Needs /root/reference, so it runs in the build container only:
 
-    python tools/make_reference_run_golden.py [yolo] [clip] [adaface] [blazeface]
+    python tools/make_reference_run_golden.py [yolo] [clip] [adaface] [blazeface] [search]
 """
 import os
 import sys
@@ -26,9 +26,15 @@ OUT = os.path.join(ROOT, "tests", "golden")
 sys.path[:0] = [os.path.join(ROOT, "tools", "refshim"), REF, ROOT]
 os.chdir(REF)                                                       # the reference opens a few files relative to its root
 
-# models/objects.py does `from clearcam import event_img_info`; importing the NVR server module itself is out of the question
+# models/objects.py does `from clearcam import event_img_info`.  Importing the NVR server module itself is out of the question
+# (ffmpeg, sockets, argparse at import time), so that one function is lifted out of clearcam.py's syntax tree and executed
+# as it stands; nothing of it is stored in this repo.
+import ast  # noqa: E402
 _cl = types.ModuleType("clearcam")
-_cl.event_img_info = lambda *a, **k: None
+_tree = ast.parse(open(os.path.join(REF, "clearcam.py")).read())
+_fn = [n for n in _tree.body if isinstance(n, ast.FunctionDef) and n.name == "event_img_info"]
+assert len(_fn) == 1
+exec(compile(ast.Module(body=_fn, type_ignores=[]), os.path.join(REF, "clearcam.py"), "exec"), _cl.__dict__)
 sys.modules["clearcam"] = _cl
 
 from tinygrad import Tensor  # noqa: E402  (the stand-in)
@@ -112,7 +118,58 @@ def run_blazeface():
     np.savez_compressed(os.path.join(OUT, "refrun_blazeface.npz"), weights_seed=555, **out)
 
 
+SEARCH_CASES = [{}, {"top_k": 3}, {"cam_name": "back"}, {"timestamp": "2026-01-02"}, {"cam_name": "front", "timestamp": "2026-01-01", "top_k": 50},
+                {"cam_name": "nowhere"}]
+
+
+def search_store(seed=31, dim=768):
+    """{crop path: (1,dim) unit vector} the way clearcam.py:1282-1287 keys it, plus the query.  Track ids repeat across crops
+    (best-per-id rule), some crops have no id, one file is not a .jpg, one day folder is the 'video' folder."""
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal(dim).astype(np.float32)
+    q /= np.linalg.norm(q)
+    store = {}
+    n = 0
+    for cam in ("front", "back", "yard"):
+        for day in ("2026-01-01", "2026-01-02", "video"):
+            for j in range(5):
+                n += 1
+                oid = (n * 7) % 11                                    # ids collide across cameras and days on purpose
+                name = f"{1700000000 + n}.0_{oid}_{n % 3}.jpg" if j != 3 else f"snapshot{n}.jpg"
+                if j == 4 and cam == "yard":
+                    name = f"notes{n}.txt"
+                v = q * rng.uniform(0.0, 0.6) + rng.standard_normal(dim).astype(np.float32) / np.sqrt(dim)
+                store[f"data/cameras/{cam}/objects/{day}/{name}"] = (v / np.linalg.norm(v)).astype(np.float32)[None]
+    return store, q
+
+
+def run_search():
+    import json
+    import pickle
+    import tempfile
+    from models.objects import ObjectFinder
+    store, q = search_store()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        folders = {}
+        for path, e in store.items():
+            folders.setdefault(os.path.dirname(path), {})[path] = e
+        for folder, emb in folders.items():                           # one embeddings.pkl per camera/day folder (clearcam.py:1286)
+            os.makedirs(folder)
+            with open(os.path.join(folder, "embeddings.pkl"), "wb") as f:
+                pickle.dump({"embeddings": emb}, f)
+        finder = ObjectFinder("data/cameras")
+        finder._load_all_embeddings()
+        assert len(finder.image_embeddings) == len(store)
+        results = [finder.search(text_embedding=q, **kw) for kw in SEARCH_CASES]
+        os.chdir(REF)
+    paths = sorted(store)
+    np.savez_compressed(os.path.join(OUT, "refrun_search.npz"), paths=np.array(paths), embs=np.concatenate([store[p] for p in paths]), query=q,
+                        cases=json.dumps(SEARCH_CASES), results=json.dumps([[[p, float(s)] for p, s in r] for r in results]))
+    print("search:", [len(r) for r in results], "top hit", results[0][0])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["yolo", "clip", "adaface", "blazeface"]
-    for w in which:
-        {"yolo": run_yolo, "clip": run_clip, "adaface": run_adaface, "blazeface": run_blazeface}[w]()
+    runs = {"yolo": run_yolo, "clip": run_clip, "adaface": run_adaface, "blazeface": run_blazeface, "search": run_search}
+    for w in sys.argv[1:] or list(runs):
+        runs[w]()
