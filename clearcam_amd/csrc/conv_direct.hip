@@ -65,38 +65,55 @@ void launch_conv_direct(int dt, const ConvP& p, hipStream_t stream) {
 // ---- pooling ---------------------------------------------------------------------------------------
 // Vector path: one thread per (pixel, 16-byte channel chunk): 8 halfs / 4 floats per load, coalesced
 // along NHWC channels (HBM-bound op: read k*k-overlapping windows through L1/L2, write once).
-template <class T>
+// Grid = (chunks of a row, output row, image).  The window is a compile-time size and every load is unconditional
+// (coordinates clamped into the image, the value replaced afterwards when the tap is padding): with a branch per tap
+// the compiler emitted load / s_waitcnt vmcnt(0) pairs, i.e. k*k dependent round trips per thread (2 TB/s); now all
+// taps of a thread are in flight together.
+template <class T> __device__ inline void unpack_chunk(const uint4& u, float (&v)[16 / sizeof(T)]) {
+  const T* t = reinterpret_cast<const T*>(&u);
+#pragma unroll
+  for (int e = 0; e < 16 / (int)sizeof(T); ++e) v[e] = to_f32<T>(t[e]);
+}
+
+template <class T, int K, int MODE>
 __global__ __launch_bounds__(256) void pool_vec_kernel(const PoolP p) {
   constexpr int E = 16 / (int)sizeof(T);
   const int CV = p.C / E;
-  const size_t total = (size_t)p.B * p.Ho * p.Wo * CV;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int cv = (int)(idx % CV);
-  const size_t m = idx / CV;
-  const int hw = p.Ho * p.Wo;
-  const int b = (int)(m / hw), rem = (int)(m - (size_t)b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= p.Wo * CV) return;
+  const int wo = x / CV, cv = x - wo * CV, ho = blockIdx.y, b = blockIdx.z;
   const T* in = reinterpret_cast<const T*>(p.in) + p.in_coff + cv * E;
   float acc[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) acc[e] = p.mode ? -INFINITY : 0.f;
-  for (int r = 0; r < p.k; ++r) {
-    const int ih = ho * p.stride - p.pad + r;
-    if ((unsigned)ih >= (unsigned)p.H) continue;
-    for (int s = 0; s < p.k; ++s) {
-      const int iw = wo * p.stride - p.pad + s;
-      if ((unsigned)iw >= (unsigned)p.W) continue;
-      const uint4 u = *reinterpret_cast<const uint4*>(in + ((size_t)(b * p.H + ih) * p.W + iw) * p.in_cstride);
-      const T* t = reinterpret_cast<const T*>(&u);
+  for (int e = 0; e < E; ++e) acc[e] = MODE ? -INFINITY : 0.f;
 #pragma unroll
-      for (int e = 0; e < E; ++e) { const float v = to_f32<T>(t[e]); acc[e] = p.mode ? fmaxf(acc[e], v) : acc[e] + v; }
+  for (int r = 0; r < K; ++r) {
+    const int ih = ho * p.stride - p.pad + r, ihc = min(max(ih, 0), p.H - 1);
+    uint4 u[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      const int iwc = min(max(wo * p.stride - p.pad + s, 0), p.W - 1);
+      u[s] = *reinterpret_cast<const uint4*>(in + ((size_t)(b * p.H + ihc) * p.W + iwc) * p.in_cstride);
+    }
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      const int iw = wo * p.stride - p.pad + s;
+      const bool ok = ih == ihc && (unsigned)iw < (unsigned)p.W;
+      float v[E];
+      unpack_chunk<T>(u[s], v);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float t = ok ? v[e] : (MODE ? -INFINITY : 0.f);         // padding: -inf for max, 0 (counted) for avg
+        acc[e] = MODE ? fmaxf(acc[e], t) : acc[e] + t;
+      }
     }
   }
   uint4 o;
   T* t = reinterpret_cast<T*>(&o);
-  const float inv = 1.0f / (float)(p.k * p.k);
+  const float inv = 1.0f / (float)(K * K);
 #pragma unroll
-  for (int e = 0; e < E; ++e) t[e] = from_f32<T>(p.mode ? acc[e] : acc[e] * inv);
+  for (int e = 0; e < E; ++e) t[e] = from_f32<T>(MODE ? acc[e] : acc[e] * inv);
+  const size_t m = ((size_t)b * p.Ho + ho) * p.Wo + wo;
   *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
 }
 
@@ -104,61 +121,52 @@ __global__ __launch_bounds__(256) void pool_vec_kernel(const PoolP p) {
 // on the same channels, in one pass: out(ho,wo) = max over the 3x3 window of pooled positions (2ho-1+r, 2wo-1+s) inside
 // [0,H-2]x[0,W-2] of the 2x2 average there.  The full-resolution averaged tensor is never written or read back.
 // Each average is summed in the order of the unfused kernel and rounding to T is monotone, so max-then-round gives
-// exactly what round-then-max gave.  The 4x4 input window lives in registers (two rows at a time).
+// exactly what round-then-max gave.  The 4x4 input window is 16 unconditional loads (clamped coordinates; a pooled
+// position outside the averaged map is skipped by index, so what a clamped tap holds never matters).
 template <class T>
 __global__ __launch_bounds__(256) void avgmax_pool_kernel(const PoolP p) {
   constexpr int E = 16 / (int)sizeof(T);
   const int CV = p.C / E;
-  const size_t total = (size_t)p.B * p.Ho * p.Wo * CV;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int cv = (int)(idx % CV);
-  const size_t m = idx / CV;
-  const int hw = p.Ho * p.Wo;
-  const int b = (int)(m / hw), rem = (int)(m - (size_t)b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= p.Wo * CV) return;
+  const int wo = x / CV, cv = x - wo * CV, ho = blockIdx.y, b = blockIdx.z;
   const T* in = reinterpret_cast<const T*>(p.in) + p.in_coff + cv * E;
   const int i0 = 2 * ho - 1, j0 = 2 * wo - 1;               // top-left input pixel of the 4x4 window
-  float prev[4][E], cur[4][E], acc[E];
+  uint4 u[4][4];
 #pragma unroll
-  for (int e = 0; e < E; ++e) acc[e] = -INFINITY;
-  auto load_row = [&](int i, float (&row)[4][E]) {
+  for (int r = 0; r < 4; ++r) {
+    const int ic = min(max(i0 + r, 0), p.H - 1);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int j = j0 + c;
-      uint4 u = make_uint4(0, 0, 0, 0);
-      if ((unsigned)i < (unsigned)p.H && (unsigned)j < (unsigned)p.W)
-        u = *reinterpret_cast<const uint4*>(in + ((size_t)(b * p.H + i) * p.W + j) * p.in_cstride);
-      const T* t = reinterpret_cast<const T*>(&u);
-#pragma unroll
-      for (int e = 0; e < E; ++e) row[c][e] = to_f32<T>(t[e]);
+      const int jc = min(max(j0 + c, 0), p.W - 1);
+      u[r][c] = *reinterpret_cast<const uint4*>(in + ((size_t)(b * p.H + ic) * p.W + jc) * p.in_cstride);
     }
-  };
-  load_row(i0, prev);
+  }
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = -INFINITY;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    load_row(i0 + r + 1, cur);
     const int ph = i0 + r;                                   // pooled row: averages input rows ph, ph+1
-    if (ph >= 0 && ph <= p.H - 2) {
+    float top[4][E], bot[4][E];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int pw = j0 + s;
-        if (pw < 0 || pw > p.W - 2) continue;
+    for (int c = 0; c < 4; ++c) { unpack_chunk<T>(u[r][c], top[c]); unpack_chunk<T>(u[r + 1][c], bot[c]); }
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const float a = (((prev[s][e] + prev[s + 1][e]) + cur[s][e]) + cur[s + 1][e]) * 0.25f;
-          acc[e] = fmaxf(acc[e], a);
-        }
+    for (int s = 0; s < 3; ++s) {
+      const int pw = j0 + s;
+      const bool ok = ph >= 0 && ph <= p.H - 2 && pw >= 0 && pw <= p.W - 2;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float a = (((top[s][e] + top[s + 1][e]) + bot[s][e]) + bot[s + 1][e]) * 0.25f;
+        acc[e] = fmaxf(acc[e], ok ? a : -INFINITY);
       }
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int e = 0; e < E; ++e) prev[c][e] = cur[c][e];
   }
   uint4 o;
   T* t = reinterpret_cast<T*>(&o);
 #pragma unroll
   for (int e = 0; e < E; ++e) t[e] = from_f32<T>(acc[e]);
+  const size_t m = ((size_t)b * p.Ho + ho) * p.Wo + wo;
   *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
 }
 
@@ -192,13 +200,20 @@ template <class T> static void launch_pool_t(const PoolP& p, hipStream_t stream)
   constexpr int E = 16 / (int)sizeof(T);
   const bool vec = p.C % E == 0 && p.in_coff % E == 0 && p.in_cstride % E == 0 && p.out_coff % E == 0 && p.out_cstride % E == 0 &&
                    ((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.out & 15) == 0;
+  const dim3 vgrid((unsigned)((p.Wo * (p.C / E) + 255) / 256), (unsigned)p.Ho, (unsigned)p.B);
   if (p.mode == 2) {
     CC_CHECK(vec && p.k == 3 && p.stride == 2 && p.pad == 1, "avg-max pool: needs 16-byte channel chunks, k=3 s=2 p=1");
-    const size_t total = (size_t)p.B * p.Ho * p.Wo * (p.C / E);
-    hipLaunchKernelGGL(avgmax_pool_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
-  } else if (vec) {
-    const size_t total = (size_t)p.B * p.Ho * p.Wo * (p.C / E);
-    hipLaunchKernelGGL(pool_vec_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(avgmax_pool_kernel<T>, vgrid, dim3(256), 0, stream, p);
+  } else if (vec && p.mode == 0 && p.k == 2) {
+    hipLaunchKernelGGL((pool_vec_kernel<T, 2, 0>), vgrid, dim3(256), 0, stream, p);
+  } else if (vec && p.mode == 1 && p.k == 1) {                       // AdaFace's MaxPool2d(1, stride) shortcut: a strided copy
+    hipLaunchKernelGGL((pool_vec_kernel<T, 1, 1>), vgrid, dim3(256), 0, stream, p);
+  } else if (vec && p.mode == 1 && p.k == 2) {                       // BlazeFace's max_pool2d(2, 2)
+    hipLaunchKernelGGL((pool_vec_kernel<T, 2, 1>), vgrid, dim3(256), 0, stream, p);
+  } else if (vec && p.mode == 1 && p.k == 3) {
+    hipLaunchKernelGGL((pool_vec_kernel<T, 3, 1>), vgrid, dim3(256), 0, stream, p);
+  } else if (vec && p.mode == 1 && p.k == 5) {
+    hipLaunchKernelGGL((pool_vec_kernel<T, 5, 1>), vgrid, dim3(256), 0, stream, p);
   } else {
     const size_t total = (size_t)p.B * p.Ho * p.Wo * p.C;
     hipLaunchKernelGGL(pool_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
