@@ -21,12 +21,9 @@ __device__ __forceinline__ int lerp_u8(int a, int b, int w7) {
 
 template <class T>
 __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
-  const size_t total = (size_t)p.B * p.Hn * p.Wn;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int x = (int)(idx % p.Wn);
-  const int y = (int)((idx / p.Wn) % p.Hn);
-  const int b = (int)(idx / ((size_t)p.Wn * p.Hn));
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;      // grid = (row tiles, row, image)
+  if (x >= p.Wn) return;
+  const size_t idx = ((size_t)b * p.Hn + y) * p.Wn + x;
   float rgb[3] = {p.pad_val, p.pad_val, p.pad_val};
   const int yy = y - p.pad_y, xx = x - p.pad_x;
   if ((unsigned)yy < (unsigned)p.nh && (unsigned)xx < (unsigned)p.nw) {
@@ -56,12 +53,19 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
     }
   }
   T* o = reinterpret_cast<T*>(p.out) + idx * p.out_c;
-  for (int c = 0; c < p.out_c; ++c) o[c] = from_f32<T>(c < 3 ? rgb[c] : 0.f);
+  if (p.out_c * (int)sizeof(T) == 16) {                         // the stem's one 16-byte channel chunk: a single store
+    uint4 v = make_uint4(0, 0, 0, 0);
+    T* t = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] = from_f32<T>(rgb[c]);
+    *reinterpret_cast<uint4*>(o) = v;
+  } else {
+    for (int c = 0; c < p.out_c; ++c) o[c] = from_f32<T>(c < 3 ? rgb[c] : 0.f);
+  }
 }
 
 void launch_preprocess(int dt, const PreP& p, hipStream_t stream) {
-  const size_t total = (size_t)p.B * p.Hn * p.Wn;
-  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  const dim3 grid((unsigned)((p.Wn + 255) / 256), (unsigned)p.Hn, (unsigned)p.B), block(256);
   if (dt == F32) hipLaunchKernelGGL(preprocess_kernel<float>, grid, block, 0, stream, p);
   else if (dt == F16) hipLaunchKernelGGL(preprocess_kernel<f16_t>, grid, block, 0, stream, p);
   else hipLaunchKernelGGL(preprocess_kernel<bf16_t>, grid, block, 0, stream, p);
