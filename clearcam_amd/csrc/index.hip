@@ -6,6 +6,7 @@
 // N*dim*4 bytes), followed by a two-stage radix-select top-k.  Scores are exact f32 dot products
 // (sequential fma per lane + wave tree), so ranking ties break by row id exactly as a stable sort would.
 #include <algorithm>
+#include <cstring>
 #include <memory>
 #include <vector>
 #include "kernels.h"
@@ -21,6 +22,7 @@ struct cc_index {
   float* scores = nullptr; size_t scores_cap = 0;
   unsigned long long* cand = nullptr; size_t cand_cap = 0;
   int* idx_dev = nullptr; float* sc_dev = nullptr; size_t out_cap = 0;
+  char* pin = nullptr; size_t pin_cap = 0;      // pinned, device-visible host staging: queries in, small results out
 };
 
 namespace {
@@ -63,6 +65,55 @@ __global__ __launch_bounds__(256) void scores_kernel(const float* __restrict__ e
   }
 }
 
+// The same scores with more memory parallelism (dim % 256 == 0, e.g. 768 / 512 / 1024): a row is covered by 16 lanes,
+// so one wave reads four rows per load instruction and keeps four independent 16-byte loads per lane in flight (16 KB
+// per wave); the queries sit in LDS; the per-row reduction is 4 shuffle steps instead of 6.  Each lane accumulates its
+// 16-byte slots in ascending order with fma, then the 16 partial sums are added as a butterfly: a fixed order, so
+// scores are deterministic and ties still break by row id.
+template <int QB>
+__global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ emb, const float* __restrict__ q, float* __restrict__ out,
+                                                    long n, int dim) {
+  extern __shared__ float4 qs[];                                  // QB x dim/4
+  const int nchunk = dim >> 2;
+  for (int i = threadIdx.x; i < QB * nchunk; i += 256) qs[i] = reinterpret_cast<const float4*>(q)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  const int steps = dim >> 6;                                     // 16 lanes x 4 floats per step; a multiple of 4
+  for (long r0 = wave * 4; r0 < n; r0 += nwaves * 4) {
+    const long row = r0 + grp;
+    const bool live = row < n;
+    const float4* e = reinterpret_cast<const float4*>(emb + (live ? row : n - 1) * dim) + sub;
+    float acc[QB];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) acc[c] = 0.f;
+    for (int t0 = 0; t0 < steps; t0 += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = e[(t0 + u) * 16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < QB; ++c) {
+          const float4 w = qs[c * nchunk + (t0 + u) * 16 + sub];
+          acc[c] = fmaf(v[u].x, w.x, acc[c]); acc[c] = fmaf(v[u].y, w.y, acc[c]); acc[c] = fmaf(v[u].z, w.z, acc[c]); acc[c] = fmaf(v[u].w, w.w, acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+      float sum = acc[c];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (sub == 0 && live) out[(long)c * n + row] = sum;
+    }
+  }
+}
+
+template <int QB> void launch_scan(cc_index* h, const float* q, float* out, hipStream_t s) {
+  const int blocks = (int)std::min<int64_t>((h->n + 15) / 16, 256 * 8);
+  hipLaunchKernelGGL(scan_kernel<QB>, dim3(blocks), dim3(256), (size_t)QB * h->dim * 4, s, h->emb, q, out, (long)h->n, h->dim);
+}
+
 __device__ __forceinline__ unsigned ordered(float f) {          // monotone float -> uint
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -78,7 +129,8 @@ __device__ void block_topk(KeyFn key, long count, int K, unsigned long long* sel
                            unsigned long long* s_prefix, int* s_k, unsigned* s_cnt) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int i = tid; i < K; i += nt) sel[i] = 0ull;
-  if (tid == 0) { *s_prefix = 0ull; *s_k = (int)(count < K ? count : K); *s_cnt = 0; }
+  __shared__ int s_done;
+  if (tid == 0) { *s_prefix = 0ull; *s_k = (int)(count < K ? count : K); *s_cnt = 0; s_done = 0; }
   __syncthreads();
   if (count <= 0) return;
   for (int byte = 7; byte >= 0; --byte) {
@@ -104,9 +156,13 @@ __device__ void block_topk(KeyFn key, long count, int K, unsigned long long* sel
         for (int qd = 3; qd >= 0; --qd) { if (cum + hh[qd] >= kk) { v = 4 * tid + qd; break; } cum += hh[qd]; }
         *s_prefix = prefix | ((unsigned long long)v << (8 * byte));
         *s_k = (int)(kk - cum);
+        // the whole bucket is wanted: every key at or above the prefix (lower bytes zero) is selected and the remaining
+        // passes would only confirm it.  With distinct scores this fires after the four score bytes (row-id bytes skipped).
+        if (hist[v] == kk - cum) s_done = 1;
       }
     }
     __syncthreads();
+    if (s_done) break;
   }
   const unsigned long long thr = *s_prefix;
   for (long i = tid; i < count; i += nt) {
@@ -139,10 +195,12 @@ __global__ __launch_bounds__(1024) void topk_stage2(const unsigned long long* __
   for (int i = tid; i < kMaxK; i += blockDim.x) sel[i] = 0ull;
   __syncthreads();
   block_topk(key, ncand, K, sel, hist, &s_prefix, &s_k, &s_cnt);
-  for (int k = 2; k <= kMaxK; k <<= 1)
+  int P = 2;                                                     // the K selected keys sit in sel[0..K): sort the next power of two
+  while (P < K) P <<= 1;
+  for (int k = 2; k <= P; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       const int ixj = tid ^ j;
-      if (ixj > tid) {
+      if (ixj > tid && ixj < P) {
         const unsigned long long x = sel[tid], y = sel[ixj];
         const bool desc = (tid & k) == 0;
         if (desc ? (x < y) : (x > y)) { sel[tid] = y; sel[ixj] = x; }
@@ -163,9 +221,26 @@ void ensure(void** p, size_t* cap, size_t bytes) {
   *cap = bytes;
 }
 
+constexpr size_t kPinResultBytes = 1 << 20;      // results up to this size are written by the kernel straight into pinned host memory
+
+void ensure_pinned(cc_index* h, size_t bytes) {
+  if (h->pin_cap >= bytes) return;
+  if (h->pin) hipHostFree(h->pin);
+  h->pin = nullptr; h->pin_cap = 0;
+  CC_HIP(hipHostMalloc((void**)&h->pin, bytes, hipHostMallocDefault));
+  h->pin_cap = bytes;
+}
+
+// Host queries go through the pinned buffer (a pageable source makes the runtime stage and block; 3 KB per query).
 void upload_queries(cc_index* h, const float* q, int Q, int on_device, hipStream_t s) {
   if (h->q_cap < Q) { if (h->q_dev) hipFree(h->q_dev); CC_HIP(hipMalloc((void**)&h->q_dev, (size_t)Q * h->dim * 4 + 256)); h->q_cap = Q; }
-  CC_HIP(hipMemcpyAsync(h->q_dev, q, (size_t)Q * h->dim * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  const size_t bytes = (size_t)Q * h->dim * 4;
+  if (!on_device && bytes <= h->pin_cap) {
+    memcpy(h->pin, q, bytes);
+    CC_HIP(hipMemcpyAsync(h->q_dev, h->pin, bytes, hipMemcpyHostToDevice, s));
+  } else {
+    CC_HIP(hipMemcpyAsync(h->q_dev, q, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  }
 }
 
 void compute_scores(cc_index* h, int Q, hipStream_t s) {
@@ -174,9 +249,25 @@ void compute_scores(cc_index* h, int Q, hipStream_t s) {
   // index rows = output channels, so every embedding is read from HBM once and scores come out (Q, N) row-major).
   // Sixteen GEMV passes for 64 queries become one.  Products are exact f32 either way; only the summation order differs
   // from the GEMV kernel (last-bit differences between the two paths).
-  if (Q > 4 && h->n % 4 == 0 && h->dim % 32 == 0) {
+  static const bool wide = [] { const char* e = getenv("CLEARCAM_SCAN"); return e ? atoi(e) != 0 : true; }();
+  const bool scan8 = wide && h->dim % 256 == 0 && h->dim <= 4096;   // scan_kernel: up to 8 queries per pass at HBM speed
+  // measured on a 125 k x 768 shard: a scan pass costs ~65 us whatever its query count (1..8), the GEMM ~220 us flat up to 128 queries
+  if (Q > (scan8 ? 16 : 4) && h->n % 4 == 0 && h->dim % 32 == 0) {
     const ConvP g = gemm_params(h->q_dev, h->dim, Q, h->dim, h->emb, h->dim, nullptr, (int)h->n, h->scores, (int)h->n, 1, 0, nullptr, 0, 0);
     if (h->n < (1L << 31) && conv_mfma_supported(F32, g)) { launch_conv_mfma(F32, g, s); return; }
+  }
+  if (scan8) {
+    for (int q0 = 0; q0 < Q; q0 += 8) {
+      const float* q = h->q_dev + (size_t)q0 * h->dim; float* out = h->scores + (size_t)q0 * h->n;
+      switch (std::min(8, Q - q0)) {
+        case 1: launch_scan<1>(h, q, out, s); break;  case 2: launch_scan<2>(h, q, out, s); break;
+        case 3: launch_scan<3>(h, q, out, s); break;  case 4: launch_scan<4>(h, q, out, s); break;
+        case 5: launch_scan<5>(h, q, out, s); break;  case 6: launch_scan<6>(h, q, out, s); break;
+        case 7: launch_scan<7>(h, q, out, s); break;  default: launch_scan<8>(h, q, out, s); break;
+      }
+    }
+    CC_HIP(hipGetLastError());
+    return;
   }
   const int blocks = (int)std::min<int64_t>((h->n + 3) / 4, 256 * 16);
   for (int q0 = 0; q0 < Q; q0 += 4) {
@@ -255,6 +346,13 @@ int cc_index_search(cc_index* h, const float* q, int Q, int k, int32_t* idx, flo
   }
   const int nchunk = (int)std::max<int64_t>(1, (h->n + kChunk - 1) / kChunk);
   ensure((void**)&h->cand, &h->cand_cap, (size_t)Q * nchunk * k * 8);
+  // Host caller with a small result (the interactive case: one query, k = 100): the merge kernel writes (id, score) into
+  // pinned host memory and the only host-side wait is the stream synchronize - no pageable copies in either direction.
+  const size_t qbytes = ((size_t)Q * h->dim * 4 + 255) & ~(size_t)255;
+  const bool zero_copy = !on_device && ob * 8 <= kPinResultBytes;
+  if (zero_copy) ensure_pinned(h, qbytes + ob * 8);
+  int* idx_out = zero_copy ? reinterpret_cast<int*>(h->pin + qbytes) : h->idx_dev;
+  float* sc_out = zero_copy ? reinterpret_cast<float*>(h->pin + qbytes + ob * 4) : h->sc_dev;
   if (h->n > 0) {
     upload_queries(h, q, Q, on_device, s);
     compute_scores(h, Q, s);
@@ -262,12 +360,18 @@ int cc_index_search(cc_index* h, const float* q, int Q, int k, int32_t* idx, flo
   } else {
     CC_HIP(hipMemsetAsync(h->cand, 0, (size_t)Q * nchunk * k * 8, s));
   }
-  hipLaunchKernelGGL(topk_stage2, dim3(Q), dim3(1024), 0, s, h->cand, (long)nchunk * k, k, h->idx_dev, h->sc_dev);
+  hipLaunchKernelGGL(topk_stage2, dim3(Q), dim3(1024), 0, s, h->cand, (long)nchunk * k, k, idx_out, sc_out);
   CC_HIP(hipGetLastError());
-  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-  CC_HIP(hipMemcpyAsync(idx, h->idx_dev, ob * 4, kind, s));
-  CC_HIP(hipMemcpyAsync(score, h->sc_dev, ob * 4, kind, s));
-  if (!on_device) CC_HIP(hipStreamSynchronize(s));
+  if (zero_copy) {
+    CC_HIP(hipStreamSynchronize(s));
+    memcpy(idx, idx_out, ob * 4);
+    memcpy(score, sc_out, ob * 4);
+  } else {
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    CC_HIP(hipMemcpyAsync(idx, h->idx_dev, ob * 4, kind, s));
+    CC_HIP(hipMemcpyAsync(score, h->sc_dev, ob * 4, kind, s));
+    if (!on_device) CC_HIP(hipStreamSynchronize(s));
+  }
   CC_API_END
 }
 
@@ -276,6 +380,7 @@ void cc_index_destroy(cc_index* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->emb, (void*)h->q_dev, (void*)h->scores, (void*)h->cand, (void*)h->idx_dev, (void*)h->sc_dev}) if (p) hipFree(p);
+  if (h->pin) hipHostFree(h->pin);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
