@@ -8,6 +8,7 @@
 // Integer/byte work (the uint8 resize) is bit-exact against the oracle; float work follows the
 // reference's operation order in f32.
 #include "kernels.h"
+#include "mfma.h"
 
 namespace cc {
 
@@ -19,39 +20,50 @@ __device__ __forceinline__ int lerp_u8(int a, int b, int w7) {
   return (a + t) & 0xff;
 }
 
+// One letterboxed pixel from its interpolation taps: rows y0/y1, columns x0/x1, fractions fx/fy (tinygrad interpolate,
+// uint8 frames through the 7-bit fixed-point lerp).  `u8(row, col, ch)` / `f32(row, col, ch)` fetch a source sample.
+template <class FetchU8, class FetchF32>
+__device__ __forceinline__ void letterbox_taps(const PreP& p, int x0, int x1, int y0, int y1, float fx, float fy, FetchU8 u8, FetchF32 f32, float (&rgb)[3]) {
+  if (!p.frame_f32) {
+    const int wx = (int)(int16_t)__fadd_rn(__fmul_rn(fx, 128.0f), 0.5f);
+    const int wy = (int)(int16_t)__fadd_rn(__fmul_rn(fy, 128.0f), 0.5f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int top = lerp_u8(u8(y0, x0, c), u8(y0, x1, c), wx);
+      const int bot = lerp_u8(u8(y1, x0, c), u8(y1, x1, c), wx);
+      rgb[p.flip ? 2 - c : c] = __fsub_rn(__fdiv_rn((float)lerp_u8(top, bot, wy), p.div), p.sub);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a0 = f32(y0, x0, c), b0 = f32(y0, x1, c);
+      const float a1 = f32(y1, x0, c), b1 = f32(y1, x1, c);
+      const float top = __fadd_rn(a0, __fmul_rn(__fsub_rn(b0, a0), fx));
+      const float bot = __fadd_rn(a1, __fmul_rn(__fsub_rn(b1, a1), fx));
+      rgb[p.flip ? 2 - c : c] = __fsub_rn(__fdiv_rn(__fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), fy)), p.div), p.sub);
+    }
+  }
+}
+
+// One pixel (b, y, x) of the letterboxed network input, as float RGB-or-BGR after v / div - sub (pad_val in the padding).
+__device__ __forceinline__ void letterbox_rgb(const PreP& p, int b, int y, int x, float (&rgb)[3]) {
+  rgb[0] = rgb[1] = rgb[2] = p.pad_val;
+  const int yy = y - p.pad_y, xx = x - p.pad_x;
+  if ((unsigned)yy < (unsigned)p.nh && (unsigned)xx < (unsigned)p.nw) {
+    const size_t img = (size_t)b * p.H;
+    auto u8 = [&](int r, int c, int ch) { return (int)reinterpret_cast<const uint8_t*>(p.frames)[((img + r) * p.W + c) * 3 + ch]; };
+    auto f32 = [&](int r, int c, int ch) { return reinterpret_cast<const float*>(p.frames)[((img + r) * p.W + c) * 3 + ch]; };
+    letterbox_taps(p, p.xlo[xx], p.xhi[xx], p.ylo[yy], p.yhi[yy], p.xfr[xx], p.yfr[yy], u8, f32, rgb);
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;      // grid = (row tiles, row, image)
   if (x >= p.Wn) return;
   const size_t idx = ((size_t)b * p.Hn + y) * p.Wn + x;
-  float rgb[3] = {p.pad_val, p.pad_val, p.pad_val};
-  const int yy = y - p.pad_y, xx = x - p.pad_x;
-  if ((unsigned)yy < (unsigned)p.nh && (unsigned)xx < (unsigned)p.nw) {
-    const int x0 = p.xlo[xx], x1 = p.xhi[xx], y0 = p.ylo[yy], y1 = p.yhi[yy];
-    const float fx = p.xfr[xx], fy = p.yfr[yy];
-    const size_t r0 = ((size_t)b * p.H + y0) * p.W, r1 = ((size_t)b * p.H + y1) * p.W;
-    if (!p.frame_f32) {
-      const uint8_t* f = reinterpret_cast<const uint8_t*>(p.frames);
-      const int wx = (int)(int16_t)__fadd_rn(__fmul_rn(fx, 128.0f), 0.5f);
-      const int wy = (int)(int16_t)__fadd_rn(__fmul_rn(fy, 128.0f), 0.5f);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int top = lerp_u8(f[(r0 + x0) * 3 + c], f[(r0 + x1) * 3 + c], wx);
-        const int bot = lerp_u8(f[(r1 + x0) * 3 + c], f[(r1 + x1) * 3 + c], wx);
-        rgb[p.flip ? 2 - c : c] = __fsub_rn(__fdiv_rn((float)lerp_u8(top, bot, wy), p.div), p.sub);
-      }
-    } else {
-      const float* f = reinterpret_cast<const float*>(p.frames);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float a0 = f[(r0 + x0) * 3 + c], b0 = f[(r0 + x1) * 3 + c];
-        const float a1 = f[(r1 + x0) * 3 + c], b1 = f[(r1 + x1) * 3 + c];
-        const float top = __fadd_rn(a0, __fmul_rn(__fsub_rn(b0, a0), fx));
-        const float bot = __fadd_rn(a1, __fmul_rn(__fsub_rn(b1, a1), fx));
-        rgb[p.flip ? 2 - c : c] = __fsub_rn(__fdiv_rn(__fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), fy)), p.div), p.sub);
-      }
-    }
-  }
+  float rgb[3];
+  letterbox_rgb(p, b, y, x, rgb);
   T* o = reinterpret_cast<T*>(p.out) + idx * p.out_c;
   if (p.out_c * (int)sizeof(T) == 16) {                         // the stem's one 16-byte channel chunk: a single store
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -62,6 +74,202 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
   } else {
     for (int c = 0; c < p.out_c; ++c) o[c] = from_f32<T>(c < 3 ? rgb[c] : 0.f);
   }
+}
+
+// ---- letterbox + first conv ---------------------------------------------------------------------------------------
+// Conv 3x3 stride 2 pad 1, 3 -> COUT, bias, SiLU (detection/yolov9.py:302 / :330, Conv :33-38) computed straight from the
+// camera frames.  A block owns a 16x16 tile of output pixels: it letterboxes the 33x33 input pixels the tile needs into
+// LDS (rounded to the storage type exactly as preprocess_kernel stores them; zeros outside the network input = the
+// conv's padding), then every output pixel is ONE v_mfma_f32_16x16x32 per 16 output channels: K = 27 (row r, column s,
+// channel c) - 9 contiguous LDS elements per row r - laid into the 32 k slots so that a lane reads whole dwords (see the
+// B-operand comment below).  The result goes through LDS so each pixel's COUT channels leave as 16-byte stores.  HBM traffic: the frames in, the activations out;
+// the (B,Hn,Wn,8) input tensor of the unfused path (a 16-byte write and read per pixel) does not exist.
+template <class T, int COUT>
+__global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
+  constexpr int PW = 33, PROW = 104;                     // patch row: 33 pixels x 3 channels (+ pad) in storage type
+  constexpr int NT = COUT / 16, OROW = COUT + 8;         // staged output row: COUT channels + 16 bytes (bank spread)
+  constexpr int SCRATCH = 256 * 72 * 2;                  // bytes: the source-pixel stage (phase 1) and the output stage (phase 3) share it
+  __shared__ T patch[PW * PROW];
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[SCRATCH];
+  __shared__ int tab_i[4][PW];                           // xlo, xhi, ylo, yhi of the patch's columns / rows
+  __shared__ float tab_f[2][PW];                         // xfr, yfr
+  __shared__ int tab_w[2][PW];                           // the 7-bit fixed-point weights of xfr, yfr (uint8 frames)
+  __shared__ T lut[256];                                 // uint8 frames: value -> value / div - sub, rounded to T
+  T* ostage = reinterpret_cast<T*>(scratch);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16, b = blockIdx.z;
+
+  // weights: A operand, row = output channel, this lane's eight k values = one 16-byte load; kept in registers for the tile
+  const int kg = lane >> 4, row = lane & 15;
+  uint4 afrag[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) afrag[nt] = reinterpret_cast<const uint4*>(p.w)[(nt * 16 + row) * 4 + kg];
+
+  // ---- phase 1: the 33x33 letterboxed pixels of this tile -> patch ------------------------------------------------
+  // Per-pixel byte loads from HBM are what bounds the stand-alone letterbox kernel (12 load instructions per pixel), so the
+  // tile's interpolation tables and - for uint8 frames whose source rectangle fits - the source bytes themselves are
+  // staged in LDS with aligned dword loads first; the taps are then LDS reads.  Arithmetic is letterbox_taps either way.
+  const PreP& q = p.pre;
+  const int Y0 = 2 * oy0 - 1, X0 = 2 * ox0 - 1;
+  if (tid < 2 * PW) {
+    const bool isx = tid < PW;
+    const int j = isx ? tid : tid - PW;
+    const int v = (isx ? X0 - q.pad_x : Y0 - q.pad_y) + j, n = isx ? q.nw : q.nh;
+    const bool ok = (unsigned)v < (unsigned)n;
+    const int vc = min(max(v, 0), n - 1);
+    tab_i[isx ? 0 : 2][j] = ok ? (isx ? q.xlo : q.ylo)[vc] : -1;          // -1: this column / row is padding
+    tab_i[isx ? 1 : 3][j] = ok ? (isx ? q.xhi : q.yhi)[vc] : -1;
+    const float fr = ok ? (isx ? q.xfr : q.yfr)[vc] : 0.f;
+    tab_f[isx ? 0 : 1][j] = fr;
+    tab_w[isx ? 0 : 1][j] = (int)(int16_t)__fadd_rn(__fmul_rn(fr, 128.0f), 0.5f);       // as letterbox_taps
+  }
+  lut[tid] = from_f32<T>(__fsub_rn(__fdiv_rn((float)tid, q.div), q.sub));
+  // source rectangle of the tile (tables are monotone): rows [sr0, sr1], columns [sc0, sc1]
+  const int yy0 = max(Y0 - q.pad_y, 0), yy1 = min(Y0 + PW - 1 - q.pad_y, q.nh - 1);
+  const int xx0 = max(X0 - q.pad_x, 0), xx1 = min(X0 + PW - 1 - q.pad_x, q.nw - 1);
+  const bool any = yy0 <= yy1 && xx0 <= xx1;
+  const int sr0 = any ? q.ylo[yy0] : 0, sr1 = any ? q.yhi[yy1] : -1, sc0 = any ? q.xlo[xx0] : 0, sc1 = any ? q.xhi[xx1] : -1;
+  const int nrows = sr1 - sr0 + 1, rowbytes = (sc1 - sc0 + 1) * 3;
+  const int dpr = (rowbytes + 6) / 4;                                   // dwords per staged row, whatever the row's misalignment
+  const bool staged = !q.frame_f32 && any && nrows * dpr * 4 <= SCRATCH;
+  if (staged) {
+    const unsigned char* fr = reinterpret_cast<const unsigned char*>(q.frames);
+    const size_t total = (size_t)q.B * q.H * q.W * 3;
+    for (int i = tid; i < nrows * dpr; i += 256) {
+      const int r = i / dpr, d = i - r * dpr;
+      const size_t a0 = (((size_t)b * q.H + sr0 + r) * q.W + sc0) * 3;  // first byte this row needs
+      const size_t al = (a0 & ~(size_t)3) + 4 * (size_t)d;
+      unsigned v = 0;
+      if (al + 4 <= total) v = *reinterpret_cast<const unsigned*>(fr + al);
+      else for (int k = 0; k < 4; ++k) if (al + k < total) v |= (unsigned)fr[al + k] << (8 * k);
+      reinterpret_cast<unsigned*>(scratch)[i] = v;
+    }
+  }
+  __syncthreads();
+  // thread -> (column tid & 31, rows tid >> 5, +8, ...): the column's taps and weights are read once; column 32 of the
+  // patch is done by the first 33 threads afterwards (pass 5)
+  for (int pass = 0; pass < 6; ++pass) {
+    const int pc = pass < 5 ? (tid & 31) : 32;
+    const int pr = pass < 5 ? (tid >> 5) + 8 * pass : tid;
+    if (pr >= PW) continue;
+    const int y = Y0 + pr, x = X0 + pc;
+    T* d = patch + pr * PROW + pc * 3;
+    const T zero = from_f32<T>(0.f);
+    d[0] = d[1] = d[2] = zero;                                          // outside the network input: the conv's zero padding
+    if ((unsigned)y >= (unsigned)q.Hn || (unsigned)x >= (unsigned)q.Wn) continue;
+    const int x0 = tab_i[0][pc], y0 = tab_i[2][pr];
+    if (x0 < 0 || y0 < 0) { d[0] = d[1] = d[2] = from_f32<T>(q.pad_val); continue; }
+    const int x1 = tab_i[1][pc], y1 = tab_i[3][pr];
+    const size_t img = (size_t)b * q.H;
+    if (!q.frame_f32) {
+      // uint8 frames: the interpolated value is an integer 0..255, so v / div - sub rounded to T is a 256-entry table
+      const int wx = tab_w[0][pc], wy = tab_w[1][pr];
+      int v[3];
+      if (staged) {
+        auto rowoff = [&](int r) {                                       // LDS byte offset of source column sc0 in row r
+          const unsigned sh = (((unsigned)(b * q.H + r) * (unsigned)q.W + (unsigned)sc0) * 3u) & 3u;
+          return (r - sr0) * dpr * 4 + (int)sh;
+        };
+        const int r0 = rowoff(y0), r1 = rowoff(y1), c0 = (x0 - sc0) * 3, c1 = (x1 - sc0) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          v[c] = lerp_u8(lerp_u8(scratch[r0 + c0 + c], scratch[r0 + c1 + c], wx), lerp_u8(scratch[r1 + c0 + c], scratch[r1 + c1 + c], wx), wy);
+      } else {
+        const uint8_t* f = reinterpret_cast<const uint8_t*>(q.frames);
+        const size_t a00 = ((img + y0) * q.W + x0) * 3, a01 = ((img + y0) * q.W + x1) * 3, a10 = ((img + y1) * q.W + x0) * 3, a11 = ((img + y1) * q.W + x1) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = lerp_u8(lerp_u8(f[a00 + c], f[a01 + c], wx), lerp_u8(f[a10 + c], f[a11 + c], wx), wy);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d[q.flip ? 2 - c : c] = lut[v[c]];
+    } else {
+      float rgb[3];
+      auto g8 = [&](int, int, int) { return 0; };
+      auto gf = [&](int r, int c, int ch) { return reinterpret_cast<const float*>(q.frames)[((img + r) * q.W + c) * 3 + ch]; };
+      letterbox_taps(q, x0, x1, y0, y1, tab_f[0][pc], tab_f[1][pr], g8, gf, rgb);
+      d[0] = from_f32<T>(rgb[0]); d[1] = from_f32<T>(rgb[1]); d[2] = from_f32<T>(rgb[2]);
+    }
+  }
+  __syncthreads();
+
+  float bias[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias[nt][i] = p.bias[nt * 16 + kg * 4 + i];
+
+  // B operand (pixels).  k slots: lane groups 0..2 take row r = group, the first 8 of that row's 9 contiguous (s, c)
+  // elements (four aligned dwords); group 3 takes element 8 of rows 0..2 and five zero slots.  stem_pack_weights uses the
+  // same order.  Every lane issues the same four ds_read_b32; group 3 masks and repacks.
+  const unsigned* patch32 = reinterpret_cast<const unsigned*>(patch);
+  int boff[4];                                                        // dword offsets relative to the pixel's first element
+#pragma unroll
+  for (int j = 0; j < 4; ++j) boff[j] = kg < 3 ? kg * (PROW / 2) + j : min(j, 2) * (PROW / 2) + 4;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int ty = wave * 4 + rr, tx = row;                         // this lane's pixel of the 16-pixel row
+    const int base = (2 * ty) * (PROW / 2) + 3 * tx;                // element 2*tx*3 of patch row 2*ty, in dwords
+    const unsigned d0 = patch32[base + boff[0]], d1 = patch32[base + boff[1]], d2 = patch32[base + boff[2]], d3 = patch32[base + boff[3]];
+    uint4 bfrag;
+    bfrag.x = kg < 3 ? d0 : ((d0 & 0xffffu) | (d1 << 16));
+    bfrag.y = kg < 3 ? d1 : (d2 & 0xffffu);
+    bfrag.z = kg < 3 ? d2 : 0u;
+    bfrag.w = kg < 3 ? d3 : 0u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      Mma<T>::run(afrag[nt], bfrag, acc);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xv = acc[i] + bias[nt][i];
+        o[i] = xv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xv * -1.4426950408889634f));   // SiLU, as conv_mfma's 16-bit epilogue
+      }
+      *reinterpret_cast<uint2*>(ostage + (ty * 16 + tx) * OROW + nt * 16 + kg * 4) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+    }
+  }
+  __syncthreads();
+  constexpr int CPP = COUT / 8;                                     // 16-byte chunks per pixel
+  for (int j = tid; j < 256 * CPP; j += 256) {
+    const int px = j / CPP, ch = j - px * CPP, ty = px >> 4, tx = px & 15;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < p.Ho && ox < p.Wo)
+      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride + p.out_coff + ch * 8) =
+          *reinterpret_cast<const uint4*>(ostage + px * OROW + ch * 8);
+  }
+}
+
+template <class T>
+__global__ void stem_pack_kernel(const T* __restrict__ w, int w_row, int cin_pad, int n, T* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * 32) return;
+  // k slot -> (row r, element q = s*3 + c): slots 0..23 = rows 0..2 x elements 0..7, slots 24..26 = element 8 of rows 0..2
+  const int co = i >> 5, k = i & 31, g = k >> 3, e = k & 7;
+  const bool live = g < 3 || e < 3;
+  const int r = g < 3 ? g : min(e, 2), q = g < 3 ? e : 8, s = q / 3, c = q - s * 3;
+  out[i] = live ? w[(size_t)co * w_row + (r * 3 + s) * cin_pad + c] : from_f32<T>(0.f);
+}
+
+void stem_pack_weights(int dt, const void* w_packed, int w_row, int cin_pad, int Cout, void* out, hipStream_t stream) {
+  const dim3 grid((Cout * 32 + 255) / 256), block(256);
+  if (dt == F16) hipLaunchKernelGGL(stem_pack_kernel<f16_t>, grid, block, 0, stream, (const f16_t*)w_packed, w_row, cin_pad, Cout, (f16_t*)out);
+  else hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)w_packed, w_row, cin_pad, Cout, (bf16_t*)out);
+  CC_HIP(hipGetLastError());
+}
+
+bool stem_fused_supported(int dt, int Cout) { return dt != F32 && (Cout == 16 || Cout == 32 || Cout == 64); }
+
+template <class T> static void launch_stem_t(const StemP& p, hipStream_t stream) {
+  const dim3 grid((unsigned)((p.Wo + 15) / 16), (unsigned)((p.Ho + 15) / 16), (unsigned)p.pre.B), block(256);
+  if (p.Cout == 64) hipLaunchKernelGGL((stem_fused_kernel<T, 64>), grid, block, 0, stream, p);
+  else if (p.Cout == 32) hipLaunchKernelGGL((stem_fused_kernel<T, 32>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((stem_fused_kernel<T, 16>), grid, block, 0, stream, p);
+}
+
+void launch_stem_fused(int dt, const StemP& p, hipStream_t stream) {
+  CC_CHECK(stem_fused_supported(dt, p.Cout) && p.out_coff % 8 == 0 && p.out_cstride % 8 == 0, "fused stem: unsupported dtype / channel count");
+  if (dt == F16) launch_stem_t<f16_t>(p, stream); else launch_stem_t<bf16_t>(p, stream);
+  CC_HIP(hipGetLastError());
 }
 
 void launch_preprocess(int dt, const PreP& p, hipStream_t stream) {

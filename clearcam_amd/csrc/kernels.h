@@ -47,6 +47,20 @@ struct PreP {                 // letterbox: detection/yolov9.py:376-379,390-404
   float div, sub, pad_val;                // inside the image: v / div - sub; in the padding: pad_val
 };
 void launch_preprocess(int dt, const PreP& p, hipStream_t stream);
+
+// Letterbox fused into the detector's first conv (3x3 stride 2, 3 -> Cout, bias + SiLU): the network-input tensor
+// (B,Hn,Wn,8) is never written or read; 16-bit storage types only (detect.hip).
+struct StemP {
+  PreP pre;                               // pre.out / pre.out_c unused
+  const void* w; const float* bias;       // [Cout][32] storage dtype from stem_pack_weights (k = r*9 + s*3 + c, zero for k >= 27), bias f32
+  int Cout;                               // 16, 32 or 64
+  void* out; int out_cstride, out_coff;   // (B,Ho,Wo,out_cstride) storage dtype
+  int Ho, Wo;                             // Hn/2, Wn/2
+};
+bool stem_fused_supported(int dt, int Cout);
+// reorder the generic conv's packed weights [Cout][w_row] (k = (r*3+s)*cin_pad + c) into the fused kernel's [Cout][32] rows
+void stem_pack_weights(int dt, const void* w_packed, int w_row, int cin_pad, int Cout, void* out, hipStream_t stream);
+void launch_stem_fused(int dt, const StemP& p, hipStream_t stream);
 // tinygrad `interpolate(mode='linear', align_corners=False)` index tables for one axis, evaluated in float32 (yolo.hip)
 void axis_tables(int n_in, int n_out, std::vector<int>& lo, std::vector<int>& hi, std::vector<float>& fr);
 

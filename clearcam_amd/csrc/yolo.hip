@@ -45,8 +45,8 @@ struct View { int buf; int coff; int C; };
 struct In { View v; int shift; };
 
 struct Op {
-  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms, 4 fuse
-  ConvP conv; PoolP pool; DecodeP dec; NmsP nms; FuseP fuse;
+  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms, 4 fuse, 5 letterbox + first conv (launched before the graph: it reads the caller's frames)
+  ConvP conv; PoolP pool; DecodeP dec; NmsP nms; FuseP fuse; StemP stem;
   double alg_macs = 0;   // algorithmic multiply-accumulates of this launch (no padding / densification)
 };
 
@@ -61,6 +61,7 @@ struct Plan {
   int in_buf = -1;
   int *xlo = nullptr, *xhi = nullptr, *ylo = nullptr, *yhi = nullptr; float *xfr = nullptr, *yfr = nullptr;
   void* frames_dev = nullptr; size_t frames_bytes = 0;
+  bool fused_stem = false; const void* last_frames = nullptr;   // no materialised network input; frames of the last detect call
   float* det = nullptr; float* out_dev = nullptr;
   hipGraphExec_t exec = nullptr;
   ~Plan() {
@@ -198,6 +199,38 @@ struct Builder {
     c.act = act;
     op.alg_macs = (double)c.B * c.Ho * c.Wo * pc.macs_px;
     P->ops.push_back(op);
+  }
+
+  // The detector's first conv straight from the frames (stem_fused_kernel); 16-bit storage only, CLEARCAM_FUSE_STEM=0 disables.
+  bool fuse_stem(int cout) const {
+    static const bool on = [] { const char* e = getenv("CLEARCAM_FUSE_STEM"); return e ? atoi(e) != 0 : true; }();
+    return on && Y->cin_pad() == 8 && stem_fused_supported(Y->dtype, cout);
+  }
+  // the fused kernel's weight layout ([Cout][32], k = r*9 + s*3 + c), derived once per handle from the packed conv weights
+  const void* stem_weights(const std::string& name, const PackedConv& pc) {
+    const std::string key = name + "#stem";
+    auto it = Y->packed.find(key);
+    if (it != Y->packed.end()) return it->second.w;
+    PackedConv f; f.cout = pc.cout;
+    CC_HIP(hipMalloc(&f.w, (size_t)pc.cout * 32 * dtype_size(Y->dtype) + 256));
+    stem_pack_weights(Y->dtype, pc.w, pc.kw, 8, pc.cout, f.w, Y->stream);
+    CC_HIP(hipStreamSynchronize(Y->stream));
+    return (Y->packed[key] = f).w;
+  }
+  void stem_fused(const std::string& name, const PackedConv& pc, View out) {
+    Op op{}; op.kind = 5; StemP& q = op.stem;
+    const Buf& ob = P->bufs[out.buf];
+    CC_CHECK(pc.k == 3 && pc.cin == 8 && ob.H == P->Hn / 2 && ob.W == P->Wn / 2 && out.C == pc.cout, "fused stem: shape mismatch");
+    PreP& pp = q.pre;
+    pp.frame_f32 = P->frame_f32; pp.B = P->B; pp.H = P->H; pp.W = P->W;
+    pp.nh = P->nh; pp.nw = P->nw; pp.pad_y = P->pad_y; pp.pad_x = P->pad_x; pp.Hn = P->Hn; pp.Wn = P->Wn;
+    pp.xlo = P->xlo; pp.xhi = P->xhi; pp.xfr = P->xfr; pp.ylo = P->ylo; pp.yhi = P->yhi; pp.yfr = P->yfr;
+    pp.flip = 1; pp.div = 255.0f; pp.sub = 0.0f; pp.pad_val = 0.0f;            // as cc_yolo_detect's preprocess launch
+    q.w = stem_weights(name, pc); q.bias = pc.bias; q.Cout = pc.cout;
+    q.out = (void*)(intptr_t)out.buf; q.out_cstride = ob.C; q.out_coff = out.coff; q.Ho = ob.H; q.Wo = ob.W;
+    op.alg_macs = (double)P->B * ob.H * ob.W * pc.macs_px;
+    P->ops.push_back(op);
+    P->fused_stem = true;
   }
 
   void pool(View in, View out, int k, int stride, int pad, int mode) {
@@ -351,7 +384,8 @@ struct Builder {
     auto stem = [&](const std::string& n, View in, int cout, int cpad) {
       const Buf& b = P->bufs[in.buf];
       const int o = new_buf(b.H / 2, b.W / 2, cout);
-      conv({{in, 0}}, pconv({n + ".conv"}, {1}, cpad), whole(o), 2, 1);
+      if (in.buf == P->in_buf && fuse_stem(cout)) stem_fused(n, pconv({n + ".conv"}, {1}, cpad), whole(o));
+      else conv({{in, 0}}, pconv({n + ".conv"}, {1}, cpad), whole(o), 2, 1);
       return whole(o);
     };
     const View y1 = stem(M + "1", whole(P->in_buf), 64, cp), y2 = stem(M + "2", y1, 128, 0);
@@ -393,7 +427,9 @@ struct Builder {
     P->in_buf = new_buf(P->Hn, P->Wn, cp);
     P->taps["input"] = P->in_buf;
     const int b0 = new_buf(P->Hn / 2, P->Wn / 2, a.stem);
-    conv({{whole(P->in_buf), 0}}, pconv({M + "0.conv"}, {1}, cp), whole(b0), 2, 1);
+    if (getenv("CLEARCAM_TAP_STEM")) P->taps["stem"] = b0;       // tests: keep the first conv's output readable (costs arena)
+    if (fuse_stem(a.stem)) stem_fused(M + "0", pconv({M + "0.conv"}, {1}, cp), whole(b0));
+    else conv({{whole(P->in_buf), 0}}, pconv({M + "0.conv"}, {1}, cp), whole(b0), 2, 1);
     const int b1 = new_buf(P->Hn / 4, P->Wn / 4, 2 * a.stem);
     conv({{whole(b0), 0}}, pconv({M + "1.conv"}, {1}), whole(b1), 2, 1);
     const View y2 = a.elan1 ? elan1(M + "2", whole(b1), a.b2_hidden, a.b2_out) : elan4(M + "2", {{whole(b1), 0}}, a.b2_hidden, a.b2_out);
@@ -437,6 +473,7 @@ struct Builder {
       else if (op.kind == 1) { touch(op.pool.in, t); touch(op.pool.out, t); }
       else if (op.kind == 2) { for (int l = 0; l < 3; ++l) touch(op.dec.raw[l], t); }
       else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) touch(op.fuse.in[k], t); touch(op.fuse.out, t); }
+      else if (op.kind == 5) touch(op.stem.out, -1);           // runs before the graph, whatever its position in the list
     }
     first[P->in_buf] = -1;                                     // written by the letterbox kernel before the first op
     for (auto& kv : P->taps) last[kv.second] = nops + 1;       // cc_yolo_get_tensor reads these after the run
@@ -484,6 +521,7 @@ struct Builder {
       } else if (op.kind == 1) { op.pool.in = ptr(op.pool.in); op.pool.out = ptr(op.pool.out); }
       else if (op.kind == 2) { for (int l = 0; l < 3; ++l) op.dec.raw[l] = (const float*)ptr(op.dec.raw[l]); op.dec.det = P->det; }
       else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) op.fuse.in[k] = ptr(op.fuse.in[k]); op.fuse.out = ptr(op.fuse.out); }
+      else if (op.kind == 5) op.stem.out = ptr(op.stem.out);
       else { op.nms.det = P->det; op.nms.out = P->out_dev; }
     }
   }
@@ -523,8 +561,15 @@ static void run_ops(cc_yolo* Y, Plan* P, hipStream_t s) {
     else if (op.kind == 1) launch_pool(Y->dtype, op.pool, s);
     else if (op.kind == 2) launch_decode(op.dec, s);
     else if (op.kind == 4) launch_fuse(Y->dtype, op.fuse, s);
+    else if (op.kind == 5) continue;                          // launched by run_stems, outside the graph
     else launch_topk_nms(op.nms, s);
   }
+}
+
+// The fused letterbox + first conv launches read the caller's frames, whose address changes from call to call, so they
+// stay outside the captured graph and run right before it.
+static void run_stems(cc_yolo* Y, Plan* P, const void* frames, hipStream_t s) {
+  for (Op& op : P->ops) if (op.kind == 5) { op.stem.pre.frames = frames; launch_stem_fused(Y->dtype, op.stem, s); }
 }
 
 static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32) {
@@ -649,7 +694,9 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
   pp.xlo = P->xlo; pp.xhi = P->xhi; pp.xfr = P->xfr; pp.ylo = P->ylo; pp.yhi = P->yhi; pp.yfr = P->yfr;
   pp.out = P->arena + P->bufs[P->in_buf].off; pp.out_c = P->bufs[P->in_buf].C;
   pp.flip = 1; pp.div = 255.0f; pp.sub = 0.0f; pp.pad_val = 0.0f;          // [..., ::-1] and / 255.0 (detection/yolov9.py:377-379)
-  launch_preprocess(h->dtype, pp, s);
+  if (P->fused_stem) run_stems(h, P, fdev, s);
+  else launch_preprocess(h->dtype, pp, s);
+  P->last_frames = fdev;
   CC_HIP(hipGraphLaunch(P->exec, s));
   CC_HIP(hipEventRecord(h->ev1, s));
   const size_t ob = (size_t)B * CC_MAX_DET * 6 * 4;
@@ -682,6 +729,14 @@ int cc_yolo_get_tensor(cc_yolo* h, const char* name, float* out, int64_t* shape,
   auto it = P->taps.find(name);
   CC_CHECK(it != P->taps.end(), std::string("unknown tensor '") + name + "'");
   const Buf& b = P->bufs[it->second];
+  if (!strcmp(name, "input") && P->fused_stem) {             // the fused stem never writes the network input: build it for the tap
+    CC_CHECK(P->last_frames, "no frames to letterbox");
+    PreP pp{};
+    for (const Op& op : P->ops) if (op.kind == 5) { pp = op.stem.pre; break; }
+    pp.frames = P->last_frames; pp.out = P->arena + b.off; pp.out_c = b.C;
+    launch_preprocess(h->dtype, pp, h->stream);
+    CC_HIP(hipStreamSynchronize(h->stream));
+  }
   const int C = !strcmp(name, "input") ? 3 : b.C;
   shape[0] = P->B; shape[1] = b.H; shape[2] = b.W; shape[3] = C; *ndim = 4;
   if (!out) return 0;
@@ -719,7 +774,7 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
   const size_t n = P->ops.size();
   std::vector<hipEvent_t> ev(2 * n);
   for (auto& e : ev) CC_HIP(hipEventCreate(&e));
-  double acc[4] = {0, 0, 0, 0}, macs = 0; int nconv = 0;
+  double acc[5] = {0, 0, 0, 0, 0}, macs = 0; int nconv = 0;
   for (int it = 0; it < iters; ++it) {
     for (size_t i = 0; i < n; ++i) {
       const Op& op = P->ops[i];
@@ -728,13 +783,15 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
       else if (op.kind == 1) launch_pool(h->dtype, op.pool, s);
       else if (op.kind == 2) launch_decode(op.dec, s);
       else if (op.kind == 4) launch_fuse(h->dtype, op.fuse, s);
+      else if (op.kind == 5) { StemP q = op.stem; q.pre.frames = P->last_frames; launch_stem_fused(h->dtype, q, s); }
       else launch_topk_nms(op.nms, s);
       CC_HIP(hipEventRecord(ev[2 * i + 1], s));
     }
     CC_HIP(hipStreamSynchronize(s));
     for (size_t i = 0; i < n; ++i) {
       float t = 0; CC_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
-      acc[P->ops[i].kind == 4 ? 1 : P->ops[i].kind] += t;
+      const int kd = P->ops[i].kind;
+      acc[kd == 4 ? 1 : (kd == 5 ? 4 : kd)] += t;               // CBFuse counts with the pools; the fused letterbox + stem has its own slot
     }
   }
   for (const Op& op : P->ops) if (op.kind == 0) { macs += op.alg_macs; ++nconv; }
@@ -757,13 +814,18 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
           const double bytes = ((double)q.B * q.H * q.W + (double)q.B * q.Ho * q.Wo) * q.C * es;
           fprintf(f, "%zu,pool%d_k%d_s%d,%.4f,%.0f,%d,0,%d,%d,%d,0,0,%.4f,%.0f\n", i, q.mode, q.k, q.stride, t, (double)q.B * q.Ho * q.Wo, q.C, q.k, q.stride, q.C,
                   bytes / 1e9, bytes / (t * 1e-3) / 1e9);
+        } else if (op.kind == 5) {
+          const StemP& q = op.stem; const double M = (double)q.pre.B * q.Ho * q.Wo, es = dtype_size(h->dtype);
+          const double bytes = (double)q.pre.B * q.pre.H * q.pre.W * 3 * (q.pre.frame_f32 ? 4 : 1) + M * q.Cout * es;
+          fprintf(f, "%zu,stem_fused,%.4f,%.0f,%d,27,3,2,3,%.4f,%.1f,%.4f,%.0f\n", i, t, M, q.Cout, op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12,
+                  bytes / 1e9, bytes / (t * 1e-3) / 1e9);
         } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : "topk_nms"), t);
       }
       fclose(f);
     }
   }
   for (auto& e : ev) hipEventDestroy(e);
-  for (int k = 0; k < 4; ++k) ms[k] = (float)(acc[k] / iters);
+  for (int k = 0; k < 5; ++k) ms[k] = (float)(acc[k] / iters);
   if (alg_macs_per_step) *alg_macs_per_step = macs;
   if (n_conv_launches) *n_conv_launches = nconv;
   CC_API_END

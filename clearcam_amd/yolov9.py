@@ -106,9 +106,9 @@ class YOLOv9:
 
     def profile(self, iters: int = 3) -> dict:
         """Per-kernel-family GPU time of the last plan (hipEvents around every launch, eager replay)."""
-        ms, macs, n = (C.c_float * 4)(), C.c_double(), C.c_int()
+        ms, macs, n = (C.c_float * 5)(), C.c_double(), C.c_int()
         _lib.check(_lib.lib().cc_yolo_profile(self._h, iters, ms, C.byref(macs), C.byref(n)))
-        return {"conv_ms": ms[0], "pool_ms": ms[1], "decode_ms": ms[2], "nms_ms": ms[3],
+        return {"conv_ms": ms[0], "pool_ms": ms[1], "decode_ms": ms[2], "nms_ms": ms[3], "stem_ms": ms[4],
                 "alg_macs_per_step": macs.value, "conv_launches": n.value}
 
     def close(self):

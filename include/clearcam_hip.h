@@ -55,8 +55,9 @@ int cc_yolo_get_tensor(cc_yolo* h, const char* name, float* out, int64_t* shape,
 /* GPU milliseconds of the last detect call's kernels (hipEvents on the launch stream). */
 int cc_yolo_last_gpu_ms(cc_yolo* h, float* ms);
 /* Eager replay of the last plan's launch list, `iters` times, with a hipEvent pair around every launch
- * on the launch stream.  ms[4] = average per-step milliseconds of {conv/GEMM, pooling, decode, top-k+NMS};
- * alg_macs_per_step = algorithmic multiply-accumulates of the conv launches (padding excluded). */
+ * on the launch stream.  ms[5] = average per-step milliseconds of {conv/GEMM, pooling, decode, top-k+NMS, fused letterbox +
+ * first conv (0 when that fusion is off: f32 mode or CLEARCAM_FUSE_STEM=0; its time is then in the conv slot and in the
+ * separate letterbox launch)}; alg_macs_per_step / n_conv_launches cover the launches timed in the conv slot. */
 int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step, int* n_conv_launches);
 void cc_yolo_destroy(cc_yolo* h);
 

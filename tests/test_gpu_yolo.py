@@ -311,3 +311,51 @@ def test_big_tile_kernel_matches_torch(case, dtype, variant):
     ref = F.silu(F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b, padding=k // 2))
     got = conv_hip(x, w, b, 1, 1, 1, dtype, force_direct=variant)        # 5: 256x256 tiles, 6: 128x128 tiles, same schedule
     assert float((got - ref).abs().max() / ref.abs().max()) <= TOL[dtype]
+
+
+_STEM_SCRIPT = r"""
+import sys, numpy as np
+from clearcam_amd.weights import synthetic_yolov9_state_dict
+from clearcam_amd.yolov9 import YOLOv9
+size, res, dtype, H, W, f32 = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+frames = np.random.default_rng(5).integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+if f32: frames = frames.astype(np.float32)
+m = YOLOv9(size, res, state_dict=synthetic_yolov9_state_dict(size, 1234), dtype=dtype, device=0)
+det = m.detect_batch(frames)
+np.savez(sys.argv[7], stem=m.get_tensor("stem"), inp=m.get_tensor("input"), det=det)
+"""
+
+
+@pytest.mark.parametrize("size,res,dtype,H,W,f32", [("t", 320, "bf16", 270, 480, 0), ("c", 640, "bf16", 640, 640, 0), ("s", 320, "f16", 320, 200, 1),
+                                                    ("t", 640, "bf16", 1080, 1920, 0),      # 3x downscale: 100-row source rectangles staged in LDS
+                                                    ("t", 320, "f16", 199, 301, 0),         # W*3 % 4 != 0: every source row starts at another byte offset
+                                                    ("s", 640, "bf16", 2160, 3840, 0),      # 6x downscale: rectangle too large for LDS, direct loads
+                                                    ("t", 320, "bf16", 90, 160, 0)])        # upscale
+def test_fused_letterbox_stem_equals_unfused(tmp_path, size, res, dtype, H, W, f32):
+    """stem_fused_kernel (letterbox + first conv from the frames) against the unfused path (preprocess_kernel -> generic conv)
+    and against the oracle's first layer: same inputs rounded the same way, one MFMA K step instead of two, so at most a
+    last-place difference of the 16-bit result; the "input" tap is rebuilt on demand and must be identical."""
+    import subprocess
+    import sys
+    outs = []
+    for fuse in ("0", "1"):
+        path = str(tmp_path / f"stem{fuse}.npz")
+        env = dict(os.environ, CLEARCAM_FUSE_STEM=fuse, CLEARCAM_TAP_STEM="1",
+                   PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", _STEM_SCRIPT, size, str(res), dtype, str(H), str(W), str(f32), path], check=True, env=env)
+        outs.append(np.load(path))
+    a, b = outs
+    assert np.array_equal(a["inp"], b["inp"])                                  # the tap is the same tensor in both modes
+    ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10                         # spacing of the storage type relative to |x| (upper bound)
+    d = np.abs(a["stem"] - b["stem"])
+    assert (d <= ulp * np.maximum(np.abs(a["stem"]), 2.0 ** -6) * 1.01).all(), float(d.max())   # one unit in the last place at most
+    assert (d > 0).mean() < 0.02                                               # and rarely that
+    # first layer of the oracle on the same (rounded) input: SiLU(conv3x3 s2)
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    sd = synthetic_yolov9_state_dict(size, 1234)
+    x = torch.from_numpy(b["inp"]).permute(0, 3, 1, 2)
+    wq = torch.from_numpy(sd["model.list.0.conv.weight"]).to(TDT[dtype]).float()
+    ref = F.silu(F.conv2d(x, wq, torch.from_numpy(sd["model.list.0.conv.bias"]), stride=2, padding=1)).permute(0, 2, 3, 1).numpy()
+    assert np.abs(b["stem"] - ref).max() <= 2 * ulp * max(1.0, float(np.abs(ref).max()))
+    n0, n1, nm, _, _ = yo.match_detections(a["det"][0], b["det"][0], 0.5)
+    assert nm >= 0.7 * max(n0, n1, 1) - 1                                      # end to end the two modes stay the same detector
