@@ -16,7 +16,7 @@ namespace cc {
 __device__ __forceinline__ int lerp_u8(int a, int b, int w7) {
   // tinygrad Tensor.lerp for uint8: int8-wrapped difference, 7-bit weight, +64, >>7, mod 256.
   const int d = (int)(int8_t)(uint8_t)(b - a);
-  const int t = (int)(((uint16_t)(int16_t)(d * w7 + 64)) >> 7);
+  const int t = (int)(((uint16_t)(int16_t)(__mul24(d, w7) + 64)) >> 7);    // |d| < 2^7, |w7| <= 2^7: a 24-bit multiply (full rate)
   return (a + t) & 0xff;
 }
 
@@ -132,63 +132,89 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
   const int nrows = sr1 - sr0 + 1, rowbytes = (sc1 - sc0 + 1) * 3;
   const int dpr = (rowbytes + 6) / 4;                                   // dwords per staged row, whatever the row's misalignment
   const bool staged = !q.frame_f32 && any && nrows * dpr * 4 <= SCRATCH;
-  if (staged) {
-    const unsigned char* fr = reinterpret_cast<const unsigned char*>(q.frames);
+  if (staged && !(p.abl & 4)) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(q.frames);
     const size_t total = (size_t)q.B * q.H * q.W * 3;
-    for (int i = tid; i < nrows * dpr; i += 256) {
-      const int r = i / dpr, d = i - r * dpr;
-      const size_t a0 = (((size_t)b * q.H + sr0 + r) * q.W + sc0) * 3;  // first byte this row needs
-      const size_t al = (a0 & ~(size_t)3) + 4 * (size_t)d;
-      unsigned v = 0;
-      if (al + 4 <= total) v = *reinterpret_cast<const unsigned*>(fr + al);
-      else for (int k = 0; k < 4; ++k) if (al + k < total) v |= (unsigned)fr[al + k] << (8 * k);
-      reinterpret_cast<unsigned*>(scratch)[i] = v;
+    // four independent dword loads per thread in flight (unconditional, index clamped), then the LDS writes
+    const int n = nrows * dpr;
+    const float inv_dpr = 1.0f / (float)dpr;
+    for (int i0 = tid; i0 < n; i0 += 1024) {
+      unsigned v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + 256 * u, n - 1);
+        int r = (int)((float)i * inv_dpr);                               // i / dpr without an integer divide
+        r += (r + 1) * dpr <= i ? 1 : 0; r -= r * dpr > i ? 1 : 0;
+        const int d = i - r * dpr;
+        // absolute addresses: an aligned dword never straddles a page, so the words holding the buffer's first and last
+        // byte are readable whatever the alignment of the caller's pointer or the size of the buffer
+        const uintptr_t a0 = base + (((size_t)b * q.H + sr0 + r) * q.W + sc0) * 3;   // first byte this row needs
+        const uintptr_t al = min((a0 & ~(uintptr_t)3) + 4 * (uintptr_t)d, (base + total - 1) & ~(uintptr_t)3);
+        v[u] = *reinterpret_cast<const unsigned*>(al);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i0 + 256 * u < n) reinterpret_cast<unsigned*>(scratch)[i0 + 256 * u] = v[u];
     }
   }
   __syncthreads();
-  // thread -> (column tid & 31, rows tid >> 5, +8, ...): the column's taps and weights are read once; column 32 of the
-  // patch is done by the first 33 threads afterwards (pass 5)
-  for (int pass = 0; pass < 6; ++pass) {
-    const int pc = pass < 5 ? (tid & 31) : 32;
-    const int pr = pass < 5 ? (tid >> 5) + 8 * pass : tid;
-    if (pr >= PW) continue;
+  // thread -> (column tid & 31, rows tid >> 5, +8, ...): whatever depends on the column only is read once; column 32 of the
+  // patch is done by the first 33 threads afterwards
+  const T zero = from_f32<T>(0.f), padv = from_f32<T>(q.pad_val);
+  const size_t img = (size_t)b * q.H;
+  const unsigned fr_lo = (unsigned)reinterpret_cast<uintptr_t>(q.frames);
+  auto pixel = [&](int pr, int pc, int x0, int x1, int wx, float fx) {
+    T o[3] = {zero, zero, zero};                                        // outside the network input: the conv's zero padding
     const int y = Y0 + pr, x = X0 + pc;
-    T* d = patch + pr * PROW + pc * 3;
-    const T zero = from_f32<T>(0.f);
-    d[0] = d[1] = d[2] = zero;                                          // outside the network input: the conv's zero padding
-    if ((unsigned)y >= (unsigned)q.Hn || (unsigned)x >= (unsigned)q.Wn) continue;
-    const int x0 = tab_i[0][pc], y0 = tab_i[2][pr];
-    if (x0 < 0 || y0 < 0) { d[0] = d[1] = d[2] = from_f32<T>(q.pad_val); continue; }
-    const int x1 = tab_i[1][pc], y1 = tab_i[3][pr];
-    const size_t img = (size_t)b * q.H;
-    if (!q.frame_f32) {
-      // uint8 frames: the interpolated value is an integer 0..255, so v / div - sub rounded to T is a 256-entry table
-      const int wx = tab_w[0][pc], wy = tab_w[1][pr];
-      int v[3];
-      if (staged) {
-        auto rowoff = [&](int r) {                                       // LDS byte offset of source column sc0 in row r
-          const unsigned sh = (((unsigned)(b * q.H + r) * (unsigned)q.W + (unsigned)sc0) * 3u) & 3u;
-          return (r - sr0) * dpr * 4 + (int)sh;
-        };
-        const int r0 = rowoff(y0), r1 = rowoff(y1), c0 = (x0 - sc0) * 3, c1 = (x1 - sc0) * 3;
+    if ((unsigned)y < (unsigned)q.Hn && (unsigned)x < (unsigned)q.Wn) {
+      const int y0 = tab_i[2][pr];
+      if (x0 < 0 || y0 < 0) o[0] = o[1] = o[2] = padv;
+      else {
+        const int y1 = tab_i[3][pr];
+        if (!q.frame_f32) {
+          // uint8 frames: the interpolated value is an integer 0..255, so v / div - sub rounded to T is a 256-entry table
+          const int wy = tab_w[1][pr];
+          int v[3];
+          if (staged) {
+            auto rowoff = [&](int r) {                                   // LDS byte offset of source column sc0 in row r
+              const unsigned sh = (fr_lo + ((unsigned)(b * q.H + r) * (unsigned)q.W + (unsigned)sc0) * 3u) & 3u;
+              return (r - sr0) * dpr * 4 + (int)sh;                      // the row's first byte, modulo its aligned dword
+            };
+            const int r0 = rowoff(y0), r1 = rowoff(y1), c0 = (x0 - sc0) * 3, c1 = (x1 - sc0) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          v[c] = lerp_u8(lerp_u8(scratch[r0 + c0 + c], scratch[r0 + c1 + c], wx), lerp_u8(scratch[r1 + c0 + c], scratch[r1 + c1 + c], wx), wy);
-      } else {
-        const uint8_t* f = reinterpret_cast<const uint8_t*>(q.frames);
-        const size_t a00 = ((img + y0) * q.W + x0) * 3, a01 = ((img + y0) * q.W + x1) * 3, a10 = ((img + y1) * q.W + x0) * 3, a11 = ((img + y1) * q.W + x1) * 3;
+            for (int c = 0; c < 3; ++c)
+              v[c] = lerp_u8(lerp_u8(scratch[r0 + c0 + c], scratch[r0 + c1 + c], wx), lerp_u8(scratch[r1 + c0 + c], scratch[r1 + c1 + c], wx), wy);
+          } else {
+            const uint8_t* f = reinterpret_cast<const uint8_t*>(q.frames);
+            const size_t a00 = ((img + y0) * q.W + x0) * 3, a01 = ((img + y0) * q.W + x1) * 3, a10 = ((img + y1) * q.W + x0) * 3, a11 = ((img + y1) * q.W + x1) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = lerp_u8(lerp_u8(f[a00 + c], f[a01 + c], wx), lerp_u8(f[a10 + c], f[a11 + c], wx), wy);
+            for (int c = 0; c < 3; ++c) v[c] = lerp_u8(lerp_u8(f[a00 + c], f[a01 + c], wx), lerp_u8(f[a10 + c], f[a11 + c], wx), wy);
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) o[q.flip ? 2 - c : c] = lut[v[c]];
+        } else {
+          float rgb[3];
+          auto g8 = [&](int, int, int) { return 0; };
+          auto gf = [&](int r, int c, int ch) { return reinterpret_cast<const float*>(q.frames)[((img + r) * q.W + c) * 3 + ch]; };
+          letterbox_taps(q, x0, x1, y0, y1, fx, tab_f[1][pr], g8, gf, rgb);
+          o[0] = from_f32<T>(rgb[0]); o[1] = from_f32<T>(rgb[1]); o[2] = from_f32<T>(rgb[2]);
+        }
       }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) d[q.flip ? 2 - c : c] = lut[v[c]];
-    } else {
-      float rgb[3];
-      auto g8 = [&](int, int, int) { return 0; };
-      auto gf = [&](int r, int c, int ch) { return reinterpret_cast<const float*>(q.frames)[((img + r) * q.W + c) * 3 + ch]; };
-      letterbox_taps(q, x0, x1, y0, y1, tab_f[0][pc], tab_f[1][pr], g8, gf, rgb);
-      d[0] = from_f32<T>(rgb[0]); d[1] = from_f32<T>(rgb[1]); d[2] = from_f32<T>(rgb[2]);
     }
+    T* d = patch + pr * PROW + pc * 3;
+    d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+  };
+  if (!(p.abl & 1)) {
+    {
+      const int pc = tid & 31;
+      const int x0 = tab_i[0][pc], x1 = tab_i[1][pc], wx = tab_w[0][pc];
+      const float fx = tab_f[0][pc];
+#pragma unroll
+      for (int pass = 0; pass < 5; ++pass) {
+        const int pr = (tid >> 5) + 8 * pass;
+        if (pr < PW) pixel(pr, pc, x0, x1, wx, fx);
+      }
+    }
+    if (tid < PW) pixel(tid, 32, tab_i[0][32], tab_i[1][32], tab_w[0][32], tab_f[0][32]);
   }
   __syncthreads();
 
@@ -223,7 +249,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float xv = acc[i] + bias[nt][i];
-        o[i] = xv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xv * -1.4426950408889634f));   // SiLU, as conv_mfma's 16-bit epilogue
+        o[i] = (p.abl & 2) ? xv : xv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xv * -1.4426950408889634f));   // SiLU, as conv_mfma's 16-bit epilogue
       }
       *reinterpret_cast<uint2*>(ostage + (ty * 16 + tx) * OROW + nt * 16 + kg * 4) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
     }
@@ -266,7 +292,9 @@ template <class T> static void launch_stem_t(const StemP& p, hipStream_t stream)
   else hipLaunchKernelGGL((stem_fused_kernel<T, 16>), grid, block, 0, stream, p);
 }
 
-void launch_stem_fused(int dt, const StemP& p, hipStream_t stream) {
+void launch_stem_fused(int dt, const StemP& p0, hipStream_t stream) {
+  StemP p = p0;
+  { static const int abl = [] { const char* e = getenv("CLEARCAM_STEM_ABL"); return e ? atoi(e) : 0; }(); p.abl = abl; }
   CC_CHECK(stem_fused_supported(dt, p.Cout) && p.out_coff % 8 == 0 && p.out_cstride % 8 == 0, "fused stem: unsupported dtype / channel count");
   if (dt == F16) launch_stem_t<f16_t>(p, stream); else launch_stem_t<bf16_t>(p, stream);
   CC_HIP(hipGetLastError());

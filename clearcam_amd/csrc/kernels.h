@@ -56,6 +56,7 @@ struct StemP {
   int Cout;                               // 16, 32 or 64
   void* out; int out_cstride, out_coff;   // (B,Ho,Wo,out_cstride) storage dtype
   int Ho, Wo;                             // Hn/2, Wn/2
+  int abl;                                // timing ablation bits (development only; 0 in production)
 };
 bool stem_fused_supported(int dt, int Cout);
 // reorder the generic conv's packed weights [Cout][w_row] (k = (r*3+s)*cin_pad + c) into the fused kernel's [Cout][32] rows
