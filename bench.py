@@ -355,7 +355,7 @@ def main() -> None:
         peak = PEAK_TFLOPS[args.dtype]
         # PMC-measured HBM traffic of the conv kernels for the headline configuration only (counters cannot be read in-process)
         default_cfg = (args.size, args.res, B, args.dtype, fh, fw) == ("c", 640, 64, "bf16", 640, 640)
-        traffic = 26.37e9 if default_cfg else None
+        traffic = 25.11e9 if default_cfg else None
         line = {
             "metric": f"yolov9{args.size}_{args.res}x{args.res}_frames_per_sec" if (fh, fw) == (args.res, args.res)
                       else f"yolov9{args.size}_{fh}x{fw}_letterbox{args.res}_frames_per_sec",
@@ -373,7 +373,7 @@ def main() -> None:
                          "hbm_side_frac": round(fps / world * 380.6e6 / 8e12, 4) if (fh, fw, args.res, args.size) == (640, 640, 640, "c") else None,
                          "traffic": traffic,
                          "traffic_note": "HBM bytes per step of the conv kernels from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                         "(profiles/r01c_yolo_bf16_b64.txt, FETCH x2 per the gfx950 correction); not re-measured in this run"
+                                         "(profiles/r01e_yolo_bf16_b64.txt, FETCH x2 per the gfx950 correction); not re-measured in this run"
                                          if traffic else None,
                          "kernel": "conv kernels: conv_mfma_kernel (all instantiations) + conv_big_kernel + conv3x3_halo_kernel + conv3x3_ws_kernel (the fused letterbox + first conv is reported under other_ms_per_step)",
                          "alg_gflop_per_step": round(alg_flops / 1e9, 2), "kernel_ms_per_step": round(prof["conv_ms"], 3),
