@@ -20,6 +20,12 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 YOLO_FILES = sorted(glob.glob(os.path.join(GOLD, "refrun_yolo_*.npz")))
 
 
+def _yolo_weights(g):
+    from clearcam_amd.weights import shift_class_bias
+    sd = synthetic_yolov9_state_dict(str(g["size"]), int(g["weights_seed"]))
+    return shift_class_bias(sd, float(g["class_bias_shift"])) if "class_bias_shift" in g and float(g["class_bias_shift"]) else sd
+
+
 def frame_of(seed, shape):
     return np.random.default_rng(int(seed)).integers(0, 256, tuple(int(s) for s in shape), dtype=np.uint8)
 
@@ -33,7 +39,9 @@ def test_yolo_hip_equals_reference_run(path):
     g = np.load(path)
     size, res, ref = str(g["size"]), int(g["res"]), g["det"]
     frame = frame_of(g["seed"], g["shape"])
-    m = YOLOv9(size, res, state_dict=synthetic_yolov9_state_dict(size, int(g["weights_seed"])), dtype="f32", device=0)
+    if "float_frame" in g and bool(g["float_frame"]):
+        frame = frame.astype(np.float32)                                 # test/run_mot.py:33-34: Tensor(frame).cast(float32)
+    m = YOLOv9(size, res, state_dict=_yolo_weights(g), dtype="f32", device=0)
     got = jit_infer(m, Tensor(frame), {}).numpy()                        # the reference's call sequence (clearcam.py:583)
     assert got.shape == (300, 6) and got.dtype == np.float32
     n_ref, n_got, n_match, box_err, sc_err = match_detections(ref, got, 0.9)

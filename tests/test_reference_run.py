@@ -20,6 +20,12 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 YOLO_FILES = sorted(glob.glob(os.path.join(GOLD, "refrun_yolo_*.npz")))
 
 
+def _yolo_weights(g):
+    from clearcam_amd.weights import shift_class_bias
+    sd = synthetic_yolov9_state_dict(str(g["size"]), int(g["weights_seed"]))
+    return shift_class_bias(sd, float(g["class_bias_shift"])) if "class_bias_shift" in g and float(g["class_bias_shift"]) else sd
+
+
 def frame_of(seed, shape):
     return np.random.default_rng(int(seed)).integers(0, 256, tuple(int(s) for s in shape), dtype=np.uint8)
 
@@ -36,7 +42,10 @@ def test_yolo_oracle_equals_reference_run(path):
     from oracle.yolov9_oracle import YOLOv9Oracle
     g = np.load(path)
     size, res, ref = str(g["size"]), int(g["res"]), g["det"]
-    got = YOLOv9Oracle(size, res, synthetic_yolov9_state_dict(size, int(g["weights_seed"])))(frame_of(g["seed"], g["shape"]))
+    frame = frame_of(g["seed"], g["shape"])
+    if "float_frame" in g and bool(g["float_frame"]):
+        frame = frame.astype(np.float32)                                    # the MOT call path: float letterbox
+    got = YOLOv9Oracle(size, res, _yolo_weights(g))(frame)
     assert got.shape == ref.shape == (300, 6)
     assert (ref[:, 4] > 0).sum() >= 9                                       # the fixture exercises top-k / NMS with real rows
     assert np.array_equal(ref[:, 4] > 0, got[:, 4] > 0)                     # the same rows survive NMS, in the same slots

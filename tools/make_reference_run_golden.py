@@ -40,13 +40,15 @@ sys.modules["clearcam"] = _cl
 from tinygrad import Tensor  # noqa: E402  (the stand-in)
 from tinygrad.nn import state  # noqa: E402
 from clearcam_amd.arch import CLIP_L14  # noqa: E402
-from clearcam_amd.weights import (synthetic_adaface_state_dict, synthetic_blazeface_state_dict,  # noqa: E402
+from clearcam_amd.weights import (shift_class_bias, synthetic_adaface_state_dict, synthetic_blazeface_state_dict,  # noqa: E402
                                   synthetic_clip_state_dict, synthetic_yolov9_state_dict)
 
 torch.set_grad_enabled(False)
 
 # (name, size, res, frame seed, frame shape): every detector size; square, letterboxed-wide and letterboxed-tall frames
+# a trailing "f32" = the MOT call path, `model(Tensor(frame).cast(float32))` (test/run_mot.py:33-34): float letterbox
 YOLO_CASES = [("t_320", "t", 320, 7, (320, 320, 3)), ("t_640_from_540x960", "t", 640, 8, (540, 960, 3)),
+              ("t_640_from_540x960_f32", "t", 640, 13, (540, 960, 3)),
               ("s_320_from_400x300", "s", 320, 9, (400, 300, 3)), ("m_320", "m", 320, 10, (320, 320, 3)),
               ("c_640", "c", 640, 11, (640, 640, 3)), ("e_640_from_360x640", "e", 640, 12, (360, 640, 3))]
 CLIP_QUERIES = ["a white van parked on the street", "person walking a dog at night"]
@@ -58,8 +60,13 @@ def frame_of(seed, shape):
 
 def run_yolo():
     from detection.yolov9 import YOLOv9
+    from tinygrad.dtype import dtypes
+    from utils.helpers import jit_infer
     for name, size, res, seed, shape in YOLO_CASES:
-        sd = dict(synthetic_yolov9_state_dict(size, 1234))
+        # float-interpolated noise is too smooth for the seeded head to fire (the uint8 path's detections ride on the int8 wrap
+        # of tinygrad's fixed-point lerp), so the float case raises every class bias by 3
+        shift = 3.0 if name.endswith("_f32") else 0.0
+        sd = dict(shift_class_bias(synthetic_yolov9_state_dict(size, 1234), shift))
         head = 42 if size == "e" else 22
         # buffers a real checkpoint carries and the constructor's strict load asks for; __call__ recomputes both (:209)
         sd[f"model.list.{head}.anchors"] = np.zeros((2, 22680), np.float32)
@@ -69,9 +76,12 @@ def run_yolo():
         model = YOLOv9(size, res)
         assert state.LOADED[-1][1] == [], f"checkpoint keys the reference model does not have: {state.LOADED[-1][1][:5]}"
         frame = frame_of(seed, shape)
-        det = model(Tensor(frame)).numpy()
+        if name.endswith("_f32"):
+            det = model(Tensor(frame).cast(dtypes.float32)).numpy()
+        else:
+            det = jit_infer(model, Tensor(frame), {}).numpy()           # the production call sequence (clearcam.py:582-583)
         np.savez_compressed(os.path.join(OUT, f"refrun_yolo_{name}.npz"), size=size, res=res, seed=seed, shape=np.array(shape),
-                            weights_seed=1234, det=det.astype(np.float32))
+                            weights_seed=1234, float_frame=name.endswith("_f32"), class_bias_shift=shift, det=det.astype(np.float32))
         print(f"yolo {name}: {(det[:, 4] > 0).sum()} detections, {time.time() - t:.1f}s")
 
 
