@@ -50,7 +50,8 @@ def test_yolo_oracle_equals_reference_run(path):
     assert (ref[:, 4] > 0).sum() >= 9                                       # the fixture exercises top-k / NMS with real rows
     assert np.array_equal(ref[:, 4] > 0, got[:, 4] > 0)                     # the same rows survive NMS, in the same slots
     assert np.array_equal(ref[:, 5], got[:, 5])                             # classes
-    assert np.abs(ref[:, :4] - got[:, :4]).max() <= 0.1                     # px (measured <= 0.04)
+    # source-frame pixels: float32 reassociation amplified by the seeded net, times 1/gain of the box back-map
+    assert np.abs(ref[:, :4] - got[:, :4]).max() <= max(0.1, 2e-4 * max(frame.shape[:2]))     # measured 0.04 px at 640, 0.22 px at 1920
     assert np.abs(ref[:, 4] - got[:, 4]).max() <= 2e-4                      # measured <= 6e-5
 
 

@@ -49,6 +49,7 @@ torch.set_grad_enabled(False)
 # a trailing "f32" = the MOT call path, `model(Tensor(frame).cast(float32))` (test/run_mot.py:33-34): float letterbox
 YOLO_CASES = [("t_320", "t", 320, 7, (320, 320, 3)), ("t_640_from_540x960", "t", 640, 8, (540, 960, 3)),
               ("t_640_from_540x960_f32", "t", 640, 13, (540, 960, 3)),
+              ("t_960_from_1080x1920", "t", 960, 14, (1080, 1920, 3)),        # the application's default: YOLOv9("t", 960) on a 1080p camera
               ("s_320_from_400x300", "s", 320, 9, (400, 300, 3)), ("m_320", "m", 320, 10, (320, 320, 3)),
               ("c_640", "c", 640, 11, (640, 640, 3)), ("e_640_from_360x640", "e", 640, 12, (360, 640, 3))]
 CLIP_QUERIES = ["a white van parked on the street", "person walking a dog at night"]
