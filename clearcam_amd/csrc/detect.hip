@@ -387,8 +387,10 @@ __global__ __launch_bounds__(1024) void topk_nms_kernel(const NmsP p) {
   const float* det = p.det + (size_t)b * p.A * 6;
   const int K = p.A < kMaxDet ? p.A : kMaxDet;
 
-  if (tid == 0) { s_prefix = 0ull; s_k = K; s_cnt = 0; }
-  // ---- radix select (MSB first, 8 bits per pass) of the K-th largest key
+  __shared__ int s_done;
+  if (tid == 0) { s_prefix = 0ull; s_k = K; s_cnt = 0; s_done = 0; }
+  // ---- radix select (MSB first, 8 bits per pass) of the K-th largest key; stops as soon as the bucket it lands in is
+  // wanted whole (distinct scores: after the four score bytes - the anchor-id bytes only matter for ties)
   for (int byte = 7; byte >= 0; --byte) {
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
@@ -414,9 +416,11 @@ __global__ __launch_bounds__(1024) void topk_nms_kernel(const NmsP p) {
         for (int q = 3; q >= 0; --q) { if (cum + hh[q] >= kk) { v = 4 * tid + q; break; } cum += hh[q]; }
         s_prefix = prefix | ((unsigned long long)v << (8 * byte));
         s_k = (int)(kk - cum);
+        if (hist[v] == kk - cum) s_done = 1;
       }
     }
     __syncthreads();
+    if (s_done) break;
   }
   // ---- collect the K keys >= threshold, pad, bitonic sort descending
   const unsigned long long thr = s_prefix;
