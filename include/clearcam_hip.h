@@ -50,7 +50,10 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
                    int frames_on_device, float* out, int out_on_device, void* stream);
 /* Parity taps: copy a named intermediate of the LAST detect call to host float32.
  * names: "input" (B,Hn,Wn,3) | "p3","p4","p5" (B,H,W,C) | "raw0","raw1","raw2" (B,H,W,144) |
- * "decoded" (B,A,6).  shape receives up to 4 dims; pass out=NULL to query the shape only. */
+ * "decoded" (B,A,6).  shape receives up to 4 dims; pass out=NULL to query the shape only.
+ * In the 16-bit modes the letterbox is fused into the first conv and "input" is rebuilt on demand, and cc_yolo_profile
+ * re-runs that kernel: for both, device frames handed to the last cc_yolo_detect call must still be alive (host frames are
+ * staged in a buffer the handle owns). */
 int cc_yolo_get_tensor(cc_yolo* h, const char* name, float* out, int64_t* shape, int* ndim);
 /* GPU milliseconds of the last detect call's kernels (hipEvents on the launch stream). */
 int cc_yolo_last_gpu_ms(cc_yolo* h, float* ms);
