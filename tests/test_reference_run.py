@@ -115,3 +115,26 @@ def test_search_restatement_equals_reference_run():
         got = search_reference(store, q, **kw)
         assert [p for p, _ in got] == [p for p, _ in ref], kw
         assert np.allclose([s for _, s in got], [s for _, s in ref], atol=1e-6)
+
+
+def test_stand_in_interpolate_equals_oracle_letterbox_resize():
+    """Two restatements of tinygrad's uint8 / float `interpolate` (the stand-in the reference run used and the oracle's
+    numpy tables) must agree bit for bit on shapes the fixtures do not cover - a guard against either one drifting."""
+    import sys
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "refshim")
+    sys.path.insert(0, shim)
+    try:
+        for k in [k for k in sys.modules if k == "tinygrad" or k.startswith("tinygrad.")]:
+            del sys.modules[k]
+        from tinygrad import Tensor
+        from oracle.yolov9_oracle import resize_bilinear
+        rng = np.random.default_rng(77)
+        for (h, w), (nh, nw) in [((37, 53), (64, 96)), ((200, 120), (75, 45)), ((1080, 1920), (360, 640)), ((90, 160), (91, 161)), ((5, 7), (5, 7))]:
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            for src in (img, img.astype(np.float32)):
+                got = Tensor(src).permute(2, 0, 1).interpolate(size=(nh, nw), mode="linear", align_corners=False).permute(1, 2, 0).numpy()
+                assert np.array_equal(got, resize_bilinear(src, nh, nw)), (h, w, nh, nw, src.dtype)
+    finally:
+        sys.path.remove(shim)
+        for k in [k for k in sys.modules if k == "tinygrad" or k.startswith("tinygrad.")]:
+            del sys.modules[k]
