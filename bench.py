@@ -383,6 +383,21 @@ def main() -> None:
                                  "kernel): its time and its 0.35 % of the FLOPs are outside achieved/frac" if prof.get("stem_ms") else None},
             "gflop_per_frame": round((alg_flops + stem_flops) / B / 1e9, 2),
         }
+        # BASELINE.json configs[0] shape of call: one frame per call (the reference's batch-1 semantics), device-resident frame,
+        # call-to-result latency including the (300,6) read-back
+        try:
+            one, lat = frames[:1].contiguous(), []
+            for _ in range(5):
+                model.detect_batch(one)
+            for _ in range(50):
+                t1 = time.perf_counter()
+                model.detect_batch(one)
+                lat.append(time.perf_counter() - t1)
+            lat.sort()
+            line["single_frame"] = {"ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "ms_p99": round(lat[-1] * 1e3, 3),
+                                    "frames_per_sec": round(1.0 / lat[len(lat) // 2], 1), "gpu_ms": round(model.last_gpu_ms(), 3)}
+        except Exception as exc:                 # noqa: BLE001  a side metric
+            line["single_frame"] = {"error": f"{type(exc).__name__}: {exc}"}
         model.close()
         if not args.no_streams and world == 1:
             line["streams"] = stream_side_metrics(local, args.size, args.res, args.dtype)
