@@ -1,0 +1,82 @@
+"""ORACLE (test infrastructure, not product code): the fp32 detector oracle with 16-bit STORAGE rounding.
+
+``YOLOv9Oracle`` (oracle/yolov9_oracle.py) restates the reference in float32.  The HIP speed modes
+(dtype f16 / bf16) keep the reference's arithmetic but store every activation and every weight in a
+16-bit type: MFMA products of 16-bit operands accumulate in f32, the epilogue (bias, SiLU, residual
+add) runs in f32 and the result is rounded ONCE when it is written (clearcam_amd/csrc/conv_mfma.hip
+``conv_epilogue``).  This class applies exactly those roundings to the oracle:
+
+  * every conv weight            -> storage type (bias stays f32)
+  * the network input  x/255     -> storage type (detect.hip ``stem_fused_kernel`` / ``preprocess_kernel``)
+  * every ``Conv`` output        -> storage type after SiLU; a RepNBottleneck's ``x + cv2(cv1(x))``
+                                    (detection/yolov9.py:89) is rounded once after the add
+  * ADown/AConv's 2x2 average    -> storage type (conv_direct.hip ``pool_vec_kernel``; max-pooling picks
+                                    an already-rounded value, so it adds nothing)
+  * the head's last 1x1 convs    -> f32 (the ``raw`` tensors are f32), decode / top-k / NMS in f32
+
+It is NOT a reference restatement and pins nothing about the reference; it predicts what a correct
+16-bit implementation can differ from the f32 oracle by, so that (a) tools/calibrate_synth.py can
+measure whether a synthetic checkpoint is well enough conditioned to test the speed modes end to end
+and (b) tests can separate "rounding the design allows" from "a kernel is wrong".  Only ``tests/`` and
+``tools/`` import it.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle.yolov9_oracle import YOLOv9Oracle
+
+_TORCH_T = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+
+class LowPrecOracle(YOLOv9Oracle):
+    def __init__(self, size: str, res: int, state_dict: Dict[str, np.ndarray], dtype: str):
+        super().__init__(size, res, state_dict)
+        self.t = _TORCH_T[dtype]
+        for k in list(self.sd):
+            if k.endswith(".weight") and self.sd[k].ndim == 4 and "dfl" not in k:
+                self.sd[k] = self.q(self.sd[k])
+
+    def q(self, x: torch.Tensor) -> torch.Tensor:
+        return x.to(self.t).to(torch.float32)
+
+    def conv(self, x, name, stride=1, groups=1):
+        return self.q(super().conv(x, name, stride, groups))
+
+    def _silu_conv_f32(self, x, name):
+        return F.silu(self._conv2d(x, name + ".conv"))
+
+    def repncsp(self, x, p):  # detection/yolov9.py:82-105; the residual add is the second conv's epilogue
+        x2 = self.conv(x, p + ".cv1")
+        for j in range(self.rep_n):
+            q = f"{p}.m.list.{j}"
+            x2 = self.q(x2 + self._silu_conv_f32(self.conv(x2, q + ".cv1"), q + ".cv2"))
+        return self.conv(torch.cat((x2, self.conv(x, p + ".cv2")), 1), p + ".cv3")
+
+    def adown(self, x, p):  # :40-52
+        x = self.q(F.avg_pool2d(x, 2, 1, 0, False, True))
+        x1, x2 = x.chunk(2, 1)
+        x1 = self.conv(x1, p + ".cv1", stride=2)
+        x2 = F.max_pool2d(x2, 3, 2, 1)
+        x2 = self.conv(x2, p + ".cv2")
+        return torch.cat((x1, x2), 1)
+
+    def aconv(self, x, p):  # :54-63
+        return self.conv(self.q(F.avg_pool2d(x, 2, 1, 0, False, True)), p + ".cv1", stride=2)
+
+    def cblinear(self, x, p, splits):  # bare conv written in the storage type
+        return self.q(self._conv2d(x, p + ".conv")).split(splits, 1)
+
+    def cbfuse(self, parts, last):  # f32 sum, one rounding (conv_direct.hip fuse_kernel)
+        return self.q(YOLOv9Oracle.cbfuse(parts, last))
+
+    def network_input(self, frames: np.ndarray) -> torch.Tensor:
+        return self.q(super().network_input(frames))
+
+
+def rel_rms(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float(torch.sqrt(((a - b) ** 2).mean() / (b ** 2).mean()))

@@ -5,9 +5,11 @@ Tolerances (BASELINE.json north_star: "box coords/classes within 1e-3"):
     (|dx| <= 1e-3 * max(H, W), i.e. 0.64 px at 640) and scores within 1e-3, with every oracle detection
     matched one-to-one by class and IoU >= 0.9.  Measured: 0.03 px / 5e-5 — the f32 round-off floor
     of a 144-conv network between two different summation orders.
-  * f16/bf16 (speed modes) are checked per layer to storage-rounding tolerance and end-to-end by
-    detection agreement; the seeded random network amplifies input perturbations ~250x over its depth,
-    so 16-bit end-to-end tolerances are necessarily loose and are stated where used.
+  * f16/bf16 (speed modes) are checked per layer to storage-rounding tolerance and end to end on the
+    well-conditioned synthetic checkpoint (perturbation gain ~1, weights bf16-exact): >= 95 % one-to-one
+    matches at IoU >= 0.9, scores within 1e-2, P3..P5 within 3e-2 / 4e-3 relative RMS, at B=64 640x640.
+    The chaotic checkpoint (gain 30-60x) is kept for the f32 gate, where its ~260 detections per frame
+    give top-k / NMS real work; its 16-bit end-to-end test is only a guard against gross breakage.
 """
 import ctypes as C
 import os
@@ -205,9 +207,73 @@ def test_decode_topk_nms_exact_given_same_logits(sd_t):
     assert np.array_equal(ref[..., 4] > 0, got[..., 4] > 0)
 
 
+# End-to-end bars of the 16-bit storage modes on the WELL-CONDITIONED checkpoint (clearcam_amd/weights.py
+# conditioned_yolov9_state_dict; measured conditioning in clearcam_amd/assets/synth_cond_report.json): at the bench
+# configuration (YOLOv9-C, B=64, 640x640) >= 95 % of the detections match the f32 oracle one-to-one by class and IoU >= 0.9,
+# scores within 1e-2, P3/P4/P5 within 3e-2 (bf16) / 4e-3 (f16) relative RMS.
+BARS_16BIT = {"bf16": 3e-2, "f16": 4e-3}
+
+
+def conditioned_case(frames, chunk=8):
+    """f32 oracle over `frames` in chunks (CPU memory): detections (B,300,6) and P3/P4/P5 as NHWC arrays."""
+    from clearcam_amd.weights import conditioned_yolov9_state_dict
+    sd = conditioned_yolov9_state_dict("c", 1234)
+    res = max(frames.shape[1:3])
+    o = yo.YOLOv9Oracle("c", res, sd)
+    det, feats = [], [[], [], []]
+    for i in range(0, len(frames), chunk):
+        det.append(o.detect_batch(frames[i:i + chunk]))
+        for l, blk in enumerate((15, 18, 21)):
+            feats[l].append(o.block_outputs[blk].permute(0, 2, 3, 1).numpy())
+    return sd, np.concatenate(det), [np.concatenate(f) for f in feats]
+
+
+def check_16bit_against_oracle(m, dtype, frames, ref, feats, min_dets):
+    got = m.detect_batch(frames)
+    for name, r in zip(("p3", "p4", "p5"), feats):
+        rel = np.sqrt(((m.get_tensor(name) - r) ** 2).mean() / (r ** 2).mean())
+        assert rel <= BARS_16BIT[dtype], (dtype, name, rel)
+    n_ref = n_got = n_match = 0
+    sc_err = 0.0
+    for b in range(len(frames)):
+        a, c, k, _, se = yo.match_detections(ref[b], got[b], 0.9)
+        n_ref += a; n_got += c; n_match += k; sc_err = max(sc_err, se)
+    assert n_ref >= min_dets, n_ref
+    assert n_match >= 0.95 * max(n_ref, n_got), (dtype, n_ref, n_got, n_match)
+    assert sc_err <= 1e-2, (dtype, sc_err)
+    return n_ref, n_got, n_match, sc_err
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_detect_16bit_modes_match_oracle_at_bench_config(dtype):
+    """The speed modes end to end at BASELINE configs[1]: B=64, 640x640, YOLOv9-C."""
+    frames = noise_frames(1, 64, 640, 640)
+    sd, ref, feats = conditioned_case(frames)
+    m = _yolo("c", 640, sd, dtype)
+    n_ref, n_got, n_match, sc_err = check_16bit_against_oracle(m, dtype, frames, ref, feats, min_dets=1000)
+    print(f"{dtype}: {n_match}/{max(n_ref, n_got)} matched at IoU>=0.9, max score err {sc_err:.2e}")
+
+
+def test_conditioned_checkpoint_f32_mode():
+    """The same checkpoint through the f32 parity mode: the tight f32 bars hold on it too."""
+    frames = noise_frames(3, 4, 640, 640)
+    sd, ref, feats = conditioned_case(frames)
+    m = _yolo("c", 640, sd, "f32")
+    got = m.detect_batch(frames)
+    for name, r in zip(("p3", "p4", "p5"), feats):
+        assert np.sqrt(((m.get_tensor(name) - r) ** 2).mean() / (r ** 2).mean()) < 2e-4, name
+    tot = [0, 0, 0]
+    for b in range(4):
+        a, c, k, be, se = yo.match_detections(ref[b], got[b], 0.9)
+        tot[0] += a; tot[1] += c; tot[2] += k
+        assert be <= 0.64 and se <= 1e-3, (be, se)
+    assert tot[0] > 50 and tot[2] >= 0.99 * max(tot[0], tot[1]) - 1, tot
+
+
 @pytest.mark.parametrize("dtype,min_match,feat_rel", [("f16", 0.85, 0.08), ("bf16", 0.55, 0.5)])
-def test_detect_16bit_modes_agree_with_oracle(dtype, min_match, feat_rel, sd_c):
-    """Speed modes, end to end.  Loose by construction (see module docstring); per-layer tests are the tight ones."""
+def test_detect_16bit_modes_on_the_chaotic_checkpoint(dtype, min_match, feat_rel, sd_c):
+    """The chaotic seeded checkpoint (perturbation gain 30-60x, see synth_cond_report.json's sibling numbers in DESIGN.md §5)
+    amplifies storage rounding; this only guards against gross breakage — the tight 16-bit bars are the two tests above."""
     frames = noise_frames(1, 2, 640, 640)
     o = yo.YOLOv9Oracle("c", 640, sd_c)
     ref = o.detect_batch(frames)
