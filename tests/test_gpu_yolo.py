@@ -215,55 +215,68 @@ BARS_16BIT = {"bf16": 3e-2, "f16": 4e-3}
 
 
 def conditioned_case(frames, chunk=8):
-    """f32 oracle over `frames` in chunks (CPU memory): detections (B,300,6) and P3/P4/P5 as NHWC arrays."""
+    """f32 oracle over `frames` in chunks (CPU memory): detections (B,300,6), P3/P4/P5 as NHWC arrays, decoded rows (B,A,6)."""
     from clearcam_amd.weights import conditioned_yolov9_state_dict
     sd = conditioned_yolov9_state_dict("c", 1234)
     res = max(frames.shape[1:3])
     o = yo.YOLOv9Oracle("c", res, sd)
-    det, feats = [], [[], [], []]
-    for i in range(0, len(frames), chunk):
-        det.append(o.detect_batch(frames[i:i + chunk]))
-        for l, blk in enumerate((15, 18, 21)):
-            feats[l].append(o.block_outputs[blk].permute(0, 2, 3, 1).numpy())
-    return sd, np.concatenate(det), [np.concatenate(f) for f in feats]
+    det, dec, feats = [], [], [[], [], []]
+    with torch.no_grad():
+        for i in range(0, len(frames), chunk):
+            x = o.network_input(frames[i:i + chunk])
+            f = o.features(x)
+            y = o.decode(o.head_raw(f))
+            dec.append(yo.decoded_rows(y))
+            det.append(o.scale_boxes(tuple(x.shape[2:]), o.postprocess(y), frames.shape[1:3]).numpy())
+            for l in range(3):
+                feats[l].append(f[l].permute(0, 2, 3, 1).numpy())
+    return sd, np.concatenate(det), [np.concatenate(f) for f in feats], np.concatenate(dec)
 
 
-def check_16bit_against_oracle(m, dtype, frames, ref, feats, min_dets):
+def check_16bit_against_oracle(m, dtype, frames, ref, feats, dec_ref, min_dets):
+    """The bars of the 16-bit modes: features, per-anchor scores of every candidate, one-to-one detection matches."""
     got = m.detect_batch(frames)
     for name, r in zip(("p3", "p4", "p5"), feats):
         rel = np.sqrt(((m.get_tensor(name) - r) ** 2).mean() / (r ** 2).mean())
         assert rel <= BARS_16BIT[dtype], (dtype, name, rel)
+    # scores within 1e-2, anchor by anchor, for every anchor either side scores over the threshold (the other side's
+    # thresholded score may read 0 when it lands just under 0.25: compare those against the threshold itself)
+    dec = m.get_tensor("decoded")
+    a, b = dec_ref[..., 4], dec[..., 4]
+    cand = (a > 0) | (b > 0)
+    same_cls = (dec_ref[..., 5] == dec[..., 5]) | (a == 0) | (b == 0)
+    sc_err = np.abs(np.where(a > 0, a, 0.25) - np.where(b > 0, b, 0.25))[cand & same_cls].max()
+    assert cand.sum() >= min_dets and sc_err <= 1e-2, (dtype, sc_err)
+    assert (same_cls[cand]).mean() >= 0.99                                   # argmax flips only between near-tied classes
     n_ref = n_got = n_match = 0
-    sc_err = 0.0
-    for b in range(len(frames)):
-        a, c, k, _, se = yo.match_detections(ref[b], got[b], 0.9)
-        n_ref += a; n_got += c; n_match += k; sc_err = max(sc_err, se)
+    for i in range(len(frames)):
+        x, y, k, _, _ = yo.match_detections(ref[i], got[i], 0.9)
+        n_ref += x; n_got += y; n_match += k
     assert n_ref >= min_dets, n_ref
     assert n_match >= 0.95 * max(n_ref, n_got), (dtype, n_ref, n_got, n_match)
-    assert sc_err <= 1e-2, (dtype, sc_err)
-    return n_ref, n_got, n_match, sc_err
+    return n_ref, n_got, n_match, float(sc_err)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_detect_16bit_modes_match_oracle_at_bench_config(dtype):
     """The speed modes end to end at BASELINE configs[1]: B=64, 640x640, YOLOv9-C."""
     frames = noise_frames(1, 64, 640, 640)
-    sd, ref, feats = conditioned_case(frames)
+    sd, ref, feats, dec_ref = conditioned_case(frames)
     m = _yolo("c", 640, sd, dtype)
-    n_ref, n_got, n_match, sc_err = check_16bit_against_oracle(m, dtype, frames, ref, feats, min_dets=1000)
+    n_ref, n_got, n_match, sc_err = check_16bit_against_oracle(m, dtype, frames, ref, feats, dec_ref, min_dets=500)
     print(f"{dtype}: {n_match}/{max(n_ref, n_got)} matched at IoU>=0.9, max score err {sc_err:.2e}")
 
 
 def test_conditioned_checkpoint_f32_mode():
     """The same checkpoint through the f32 parity mode: the tight f32 bars hold on it too."""
-    frames = noise_frames(3, 4, 640, 640)
-    sd, ref, feats = conditioned_case(frames)
+    frames = noise_frames(3, 8, 640, 640)
+    sd, ref, feats, _ = conditioned_case(frames)
     m = _yolo("c", 640, sd, "f32")
     got = m.detect_batch(frames)
     for name, r in zip(("p3", "p4", "p5"), feats):
         assert np.sqrt(((m.get_tensor(name) - r) ** 2).mean() / (r ** 2).mean()) < 2e-4, name
     tot = [0, 0, 0]
-    for b in range(4):
+    for b in range(8):
         a, c, k, be, se = yo.match_detections(ref[b], got[b], 0.9)
         tot[0] += a; tot[1] += c; tot[2] += k
         assert be <= 0.64 and se <= 1e-3, (be, se)

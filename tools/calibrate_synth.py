@@ -66,7 +66,7 @@ def calibrate(size: str, seed: int = 1234, res: int = 640):
 
 # ---- the well-conditioned checkpoint ---------------------------------------------------------------------------------
 
-def calibrate_conditioned(size: str, seed: int = 1234, res: int = 640, n_frames: int = 2):
+def calibrate_conditioned(size: str, seed: int = 1234, res: int = 640, n_frames: int = 8):
     """-> table {"g:<conv>": gain (scalar, or per output channel in the head), "b:<conv>": bias shift per channel, "j:<conv>": jitter}."""
     o = YOLOv9Oracle(size, res, W.conditioned_base_weights(size, seed))      # unit gains, the seeded N(0,1) bias draws
     base_bias = {k: v.clone() for k, v in o.sd.items() if k.endswith(".bias")}
