@@ -17,7 +17,8 @@ SYMBOLS = [
     "cc_blaze_create", "cc_blaze_load", "cc_blaze_finalize", "cc_blaze_detect", "cc_blaze_destroy",
     "cc_face_create", "cc_face_load", "cc_face_finalize", "cc_face_embed", "cc_face_destroy",
     "cc_ocsort_create", "cc_ocsort_update", "cc_ocsort_update_many", "cc_ocsort_num_tracks", "cc_ocsort_destroy",
-    "cc_index_create", "cc_index_add", "cc_index_size", "cc_index_scores", "cc_index_search", "cc_index_destroy",
+    "cc_index_create", "cc_index_create_ex", "cc_index_add", "cc_index_add_grouped", "cc_index_size", "cc_index_info", "cc_index_scores",
+    "cc_index_search", "cc_index_search_groups", "cc_index_destroy",
 ]
 
 
@@ -84,7 +85,11 @@ def lib() -> C.CDLL:
         "cc_ocsort_update_many": [vp, C.c_int, vp, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int],
         "cc_ocsort_num_tracks": [vp, ip],
         "cc_index_create": [C.POINTER(vp), C.c_int, C.c_int64, C.c_int],
+        "cc_index_create_ex": [C.POINTER(vp), C.c_int, C.c_int64, C.c_int, C.c_int],
         "cc_index_add": [vp, vp, C.c_int64, C.c_int],
+        "cc_index_add_grouped": [vp, vp, C.c_int64, C.c_int, vp],
+        "cc_index_info": [vp, i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "cc_index_search_groups": [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp],
         "cc_index_size": [vp, i64p],
         "cc_index_scores": [vp, vp, C.c_int, vp, C.c_int, vp],
         "cc_index_search": [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp],

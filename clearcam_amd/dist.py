@@ -42,36 +42,55 @@ def merge_topk(all_idx: torch.Tensor, all_score: torch.Tensor, k: int) -> Tuple[
     return torch.gather(i1, 1, o2), torch.gather(s1, 1, o2)
 
 
-def allgather_topk(local_idx, local_score, row_offset: int, k: int, group=None,
-                   device: Optional[torch.device] = None) -> Tuple[np.ndarray, np.ndarray]:
-    """The one exchange step of sharded search.
+def allgather_topk_device(local_idx: torch.Tensor, local_score: torch.Tensor, row_offset: int, k: int,
+                          group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The one exchange step of sharded search, tensors in, tensors out, on whatever device they live on.
 
-    local_idx/local_score: (Q,k) per-rank top-k with LOCAL row ids (-1 / -inf padding).  Returns the merged
-    global (Q,k) ids and scores, identical on every rank."""
-    idx = torch.as_tensor(np.asarray(local_idx), dtype=torch.int64, device=device)
-    sc = torch.as_tensor(np.asarray(local_score), dtype=torch.float32, device=device)
+    local_idx (int32/int64) / local_score (f32): (Q,k) per-rank top-k with LOCAL row ids (-1 / -inf padding).  Returns the
+    merged global (Q,k) int64 ids and f32 scores, identical on every rank.  With CUDA tensors and the "nccl" backend
+    (RCCL) nothing touches the host: one all-gather of (Q, 2, k) int64 per rank, then two sorts on the GPU."""
+    idx = local_idx.to(torch.int64)
     idx = torch.where(idx >= 0, idx + row_offset, idx)
     # one message per rank: (Q, 2, k) int64 = [global ids | float32 score bits]
-    packed = torch.stack([idx, sc.view(torch.int32).to(torch.int64)], dim=1).contiguous()
+    packed = torch.stack([idx, local_score.contiguous().view(torch.int32).to(torch.int64)], dim=1).contiguous()
     world = dist.get_world_size(group)
     parts = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(parts, packed, group=group)
     gi = torch.cat([t[:, 0] for t in parts], 1)
     gs = torch.cat([t[:, 1].to(torch.int32).view(torch.float32) for t in parts], 1)
-    mi, ms = merge_topk(gi, gs, k)
+    return merge_topk(gi, gs, k)
+
+
+def allgather_topk(local_idx, local_score, row_offset: int, k: int, group=None,
+                   device: Optional[torch.device] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Host-array form of `allgather_topk_device` (numpy in, numpy out; the exchange itself runs on `device`)."""
+    idx = torch.as_tensor(np.asarray(local_idx), dtype=torch.int64, device=device)
+    sc = torch.as_tensor(np.asarray(local_score), dtype=torch.float32, device=device)
+    mi, ms = allgather_topk_device(idx, sc, row_offset, k, group)
     return mi.cpu().numpy(), ms.cpu().numpy()
 
 
 class ShardedIndex:
-    """Row-sharded embedding index: local HBM scan + one RCCL all-gather of k candidates per rank."""
+    """Row-sharded embedding index: local HBM scan + one RCCL all-gather of k candidates per rank.  When the local index
+    can leave its result on the GPU (`search_device`, the HIP EmbeddingIndex) the candidate lists go scan -> all-gather ->
+    merge without visiting the host; `search` copies the merged (Q,k) result out once, `search_device` not at all."""
 
     def __init__(self, index, group=None, device: Optional[torch.device] = None):
         self.index, self.group, self.device = index, group, device
         self.row_offset, self.total = shard_offsets(len(index), group, device)
 
+    def search_device(self, q, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        if hasattr(self.index, "search_device") and self.device is not None and torch.device(self.device).type == "cuda":
+            idx, sc = self.index.search_device(q, k)
+        else:                                                # CPU / gloo (tests) or an index without a device-side result
+            i, s = self.index.search(q, k)
+            idx = torch.as_tensor(np.asarray(i), dtype=torch.int64, device=self.device)
+            sc = torch.as_tensor(np.asarray(s), dtype=torch.float32, device=self.device)
+        return allgather_topk_device(idx, sc, self.row_offset, k, self.group)
+
     def search(self, q, k: int):
-        idx, sc = self.index.search(q, k)
-        return allgather_topk(idx, sc, self.row_offset, k, self.group, self.device)
+        mi, ms = self.search_device(q, k)
+        return mi.cpu().numpy(), ms.cpu().numpy()
 
 
 def allgather_rows(rows: torch.Tensor, group=None) -> Tuple[torch.Tensor, Sequence[int]]:

@@ -69,12 +69,12 @@ def as_numpy(x) -> np.ndarray:
 
 
 def jit_infer(fn, x, jit_cache):
-    """``utils/helpers.py:214-221``: memoise one compiled callable per input shape.
+    """``utils/helpers.py:214-221``: one compiled graph per input shape, the callable passed on EVERY call.
 
-    The HIP runtime keeps its own per-shape plan (buffers + captured hipGraph) inside the model
-    handle, so the cache entry here is just the callable; the signature and the
-    ``settings change -> jit_cache.clear()`` behaviour (clearcam.py:1260-1262) stay the same."""
-    shape = tuple(x.shape)
-    if shape not in jit_cache:
-        jit_cache[shape] = fn
-    return jit_cache[shape](x)
+    The reference stores ``TinyJit(lambda x, fn: fn(x))`` per shape and calls ``jit_cache[shape](x, fn)``: the cache
+    entry never binds a model, so clearcam.py can close and re-create its CLIP model (settings toggle, :1250-1253) or
+    run two models over inputs of one shape without ever clearing ``jit_cache``.  Here the per-shape plan (buffers +
+    captured hipGraph) lives inside the model handle, so the entry only records that the shape has been seen
+    (``jit_cache.clear()`` on a settings change, clearcam.py:1260-1262, keeps working)."""
+    jit_cache.setdefault(tuple(x.shape), True)
+    return fn(x)

@@ -114,22 +114,45 @@ class OpenCLIP:
 
 
 class EmbeddingIndex:
-    """Device-resident (N,dim) float32 matrix with scan + top-k (cc_index_*)."""
+    """Device-resident (N,dim) matrix with scan + top-k (cc_index_*).  storage "f32" (exact f32 scores) or "bf16" (half the
+    bytes per scan, scores within ~1e-3 for unit vectors).  `capacity` is the initial allocation; the matrix grows."""
 
-    def __init__(self, dim: int = 768, capacity: int = 1 << 20, device: int = 0):
-        self.dim, self.capacity, self.device = dim, capacity, device
+    def __init__(self, dim: int = 768, capacity: int = 1 << 20, device: int = 0, storage: str = "f32"):
+        self.dim, self.device, self.storage = dim, device, storage
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().cc_index_create(C.byref(self._h), dim, capacity, device))
+        _lib.check(_lib.lib().cc_index_create_ex(C.byref(self._h), dim, max(int(capacity), 1), device, {"f32": 0, "bf16": 2}[storage]))
+
+    @property
+    def capacity(self) -> int:
+        c = C.c_int64()
+        _lib.check(_lib.lib().cc_index_info(self._h, C.byref(c), None, None))
+        return c.value
 
     def __len__(self) -> int:
         n = C.c_int64()
         _lib.check(_lib.lib().cc_index_size(self._h, C.byref(n)))
         return n.value
 
-    def add(self, emb) -> None:
+    def add(self, emb, groups=None) -> None:
+        """Append rows: (n,dim) / (n,1,dim) / (dim,) float32, host array or CUDA torch tensor.  Rows of any other width are
+        rejected (a 512-d face row must never land in the 768-d crop matrix).  groups: one int per row (search filter unit)."""
         on_dev = bool(getattr(emb, "is_cuda", False))
-        a = emb.contiguous().float() if on_dev else np.ascontiguousarray(as_numpy(emb), dtype=np.float32).reshape(-1, self.dim)
-        _lib.check(_lib.lib().cc_index_add(self._h, _lib.ptr(a), a.shape[0], int(on_dev)))
+        if on_dev:
+            a = emb.contiguous().float()
+            if a.shape[-1] != self.dim:
+                raise ValueError(f"expected {self.dim}-d rows, got {tuple(a.shape)}")
+            a = a.reshape(-1, self.dim)
+        else:
+            a = np.asarray(as_numpy(emb), dtype=np.float32)
+            if a.ndim == 0 or a.shape[-1] != self.dim:
+                raise ValueError(f"expected {self.dim}-d rows, got {a.shape}")
+            a = np.ascontiguousarray(a.reshape(-1, self.dim))
+        g = None
+        if groups is not None:
+            g = np.ascontiguousarray(np.asarray(groups, np.int32).reshape(-1))
+            if g.shape[0] != a.shape[0] or (g.size and (g.min() < 0 or g.max() >= 1 << 24)):
+                raise ValueError("groups: one id in [0, 2^24) per row")
+        _lib.check(_lib.lib().cc_index_add_grouped(self._h, _lib.ptr(a), a.shape[0], int(on_dev), _lib.ptr(g) if g is not None else None))
 
     def scores(self, q) -> np.ndarray:
         qa = np.ascontiguousarray(as_numpy(q), dtype=np.float32).reshape(-1, self.dim)
@@ -138,12 +161,28 @@ class EmbeddingIndex:
             _lib.check(_lib.lib().cc_index_scores(self._h, _lib.ptr(qa), qa.shape[0], _lib.ptr(out), 0, None))
         return out
 
-    def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
-        """(Q,dim) queries -> (idx (Q,k) int32, score (Q,k) f32), descending, ties by lower row id; -1/-inf past N."""
+    def search(self, q, k: int, allowed=None) -> Tuple[np.ndarray, np.ndarray]:
+        """(Q,dim) queries -> (idx (Q,k) int32, score (Q,k) f32), descending, ties by lower row id; -1/-inf past N.
+        allowed: optional uint8 array, one entry per group id — only rows of groups with a non-zero entry compete."""
         qa = np.ascontiguousarray(as_numpy(q), dtype=np.float32).reshape(-1, self.dim)
         idx = np.empty((qa.shape[0], k), np.int32)
         sc = np.empty((qa.shape[0], k), np.float32)
-        _lib.check(_lib.lib().cc_index_search(self._h, _lib.ptr(qa), qa.shape[0], k, _lib.ptr(idx), _lib.ptr(sc), 0, None))
+        al = None if allowed is None else np.ascontiguousarray(allowed, dtype=np.uint8)
+        _lib.check(_lib.lib().cc_index_search_groups(self._h, _lib.ptr(qa), qa.shape[0], k, _lib.ptr(al) if al is not None else None,
+                                                     0 if al is None else int(al.size), _lib.ptr(idx), _lib.ptr(sc), 0, None))
+        return idx, sc
+
+    def search_device(self, q, k: int):
+        """The same with the result left on the GPU: (idx int32, score f32) CUDA torch tensors on the current torch stream,
+        for callers that keep going on the device (clearcam_amd.dist.ShardedIndex: all-gather + merge)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        on_dev = bool(getattr(q, "is_cuda", False))
+        qa = q.contiguous().float().reshape(-1, self.dim) if on_dev else np.ascontiguousarray(as_numpy(q), dtype=np.float32).reshape(-1, self.dim)
+        idx = torch.empty((qa.shape[0], k), dtype=torch.int32, device=dev)
+        sc = torch.empty((qa.shape[0], k), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib().cc_index_search_groups(self._h, _lib.ptr(qa), qa.shape[0], k, None, 0, _lib.ptr(idx), _lib.ptr(sc), 1, C.c_void_p(stream)))
         return idx, sc
 
     def close(self):
@@ -156,6 +195,68 @@ class EmbeddingIndex:
             self.close()
         except Exception:
             pass
+
+
+class _RowTable:
+    """Host-side description of the rows of one device matrix, built ONCE when rows are added, so that a search costs
+    O(groups + candidates) Python instead of the reference's O(N) loop (models/objects.py:365-376).
+
+    The reference filters a crop by two substring tests on its '/'-normalised path — f"/cameras/{cam}/" and
+    f"/objects/{day}/" or "/objects/video/" (:368-371).  Both patterns end in '/', so they can only match inside the
+    directory part of the path: rows are grouped by directory string and the tests run once per group.  Group 0 holds the
+    rows the reference never returns (file name not *.jpg, :374)."""
+
+    def __init__(self):
+        self.paths: List[str] = []
+        self.dirs: List[str] = [""]            # group id -> directory part (group 0: never allowed)
+        self.dir_id: Dict[str, int] = {}
+        self.truthy: List[bool] = [False]      # group has a crop whose track id is truthy (the `any(item[2] ...)` of :378)
+        self.bad: List[bool] = [False]         # group has a *.jpg name event_img_info cannot parse (the reference raises on it)
+        self.group: List[int] = []
+        self.oid: List[int] = []               # track id per row, -1 = None (no '_' in the name)
+
+    def describe(self, path: str) -> Tuple[int, int]:
+        norm = path.replace("\\", "/")
+        fn = os.path.basename(path)
+        if not fn.lower().endswith(".jpg"):
+            return 0, -1
+        d = norm[:norm.rfind("/") + 1]
+        g = self.dir_id.get(d)
+        if g is None:
+            g = self.dir_id[d] = len(self.dirs)
+            self.dirs.append(d); self.truthy.append(False); self.bad.append(False)
+        oid = -1
+        if "_" in fn:
+            try:
+                oid = event_img_info(fn.split(".jpg")[0])["object_id"]
+                if oid < 0 or oid >= 1 << 62:
+                    raise ValueError
+            except Exception:                  # noqa: BLE001  unparsable / negative ids take the exact slow path at search time
+                self.bad[g] = True
+                oid = -1
+        if oid > 0:
+            self.truthy[g] = True
+        return g, oid
+
+    def extend(self, paths) -> np.ndarray:
+        groups = np.empty(len(paths), np.int32)
+        for i, p in enumerate(paths):
+            g, oid = self.describe(p)
+            groups[i] = g
+            self.group.append(g); self.oid.append(oid)
+        self.paths.extend(paths)
+        return groups
+
+    def allowed(self, cam_name, timestamp) -> np.ndarray:
+        al = np.zeros(len(self.dirs), np.uint8)
+        for g in range(1, len(self.dirs)):
+            d = self.dirs[g]
+            if cam_name and f"/cameras/{cam_name}/" not in d:
+                continue
+            if timestamp and f"/objects/{timestamp}/" not in d and "/objects/video/" not in d:
+                continue
+            al[g] = 1
+        return al
 
 
 def preprocess_crops(crops, size: int = 224, device: int = 0):
@@ -189,9 +290,13 @@ class ObjectFinder:
         self.clip = False
         self.jit_cache: dict = {}
         self.model: Optional[OpenCLIP] = None
-        self._index: Optional[EmbeddingIndex] = None
-        self._index_paths: List[str] = []
-        self._index_src = None
+        # one device matrix + row table per source: "store" (attach_store), "image" / "face" (the reference's dicts).
+        # They never share state: a face search cannot replace the attached crop matrix, and 512-d rows cannot enter it.
+        self._dev: Dict[str, Tuple[EmbeddingIndex, _RowTable]] = {}
+        self._dev_sig: Dict[str, tuple] = {}
+        self._version = {"image": 0, "face": 0}
+        self._stores: Dict[str, object] = {}
+        self.index_storage = "f32"             # "bf16" halves the scan bytes (scores within ~1e-3)
 
     def init_clip(self, **clip_kwargs):
         """:199-206 (warm-up included: the first call per shape builds and captures the hipGraph)."""
@@ -301,38 +406,70 @@ class ObjectFinder:
 
     # -- store ------------------------------------------------------------------------------------
     def _load_all_embeddings(self, face: bool = False):
-        """:392-422 — merge every per-day embeddings.pkl under base_path, drop stale keys."""
+        """:392-422 — merge every per-day embeddings.pkl under base_path, drop stale keys.  Folders written by
+        `add_embedding` (append-only store files, clearcam_amd/store.py) are read as well, so the rows this class itself
+        stored are not mistaken for stale keys."""
+        from .store import EmbeddingStore
         valid, target = set(), (self.face_embeddings if face else self.image_embeddings)
+        key = "face" if face else "image"
+        files = []
         if os.path.isdir(self.base_path):
             for cam in os.listdir(self.base_path):
                 objects = os.path.join(self.base_path, cam, "faces" if face else "objects")
                 if not os.path.isdir(objects):
                     continue
                 for day in os.listdir(objects):
-                    f = os.path.join(objects, day, "embeddings.pkl")
-                    if not os.path.exists(f):
-                        continue
-                    with open(f, "rb") as fh:
-                        emb = pickle.load(fh).get("embeddings", {})
-                    valid.update(emb.keys())
-                    target.update(emb)
+                    for name in ("embeddings.pkl", "embeddings.idx", "embeddings.f32"):
+                        f = os.path.join(objects, day, name)
+                        if os.path.exists(f):
+                            st_ = os.stat(f)
+                            files.append((f, st_.st_mtime_ns, st_.st_size))
+        sig = (tuple(sorted(files)), len(target))
+        if getattr(self, "_files_sig", {}).get(key) == sig:
+            return                                           # nothing on disk changed since the last reload: keep dict and device matrix
+        for folder in sorted({os.path.dirname(f) for f, _, _ in files}):
+            f = os.path.join(folder, "embeddings.pkl")
+            if os.path.exists(f):
+                with open(f, "rb") as fh:
+                    emb = pickle.load(fh).get("embeddings", {})
+                valid.update(emb.keys())
+                target.update(emb)
+            if os.path.exists(os.path.join(folder, "embeddings.idx")):
+                st = EmbeddingStore(folder, 512 if face else 768)
+                rows = st.rows()
+                for i, p in enumerate(st.paths()):
+                    valid.add(p)
+                    target[p] = np.array(rows[i:i + 1])
         for k in set(target) - valid:
             del target[k]
+        self._version[key] += 1
+        if not hasattr(self, "_files_sig"):
+            self._files_sig = {}
+        self._files_sig[key] = (sig[0], len(target))
 
     # -- append-only store (clearcam_amd/store.py) instead of one pickle per folder ---------------------------
+    def _new_index(self, dim: int, rows: int) -> EmbeddingIndex:
+        return EmbeddingIndex(dim, max(2 * rows, 1024), device=self.model.device if self.model else 0, storage=self.index_storage)
+
+    def _replace(self, key: str, index: EmbeddingIndex, table: "_RowTable"):
+        old = self._dev.pop(key, None)
+        if old is not None:
+            old[0].close()
+        self._dev[key] = (index, table)
+
     def attach_store(self, capacity: Optional[int] = None) -> int:
         """Load every stored crop under base_path (store files and/or the reference's pickles) straight into the device
-        matrix: no per-crop dict entries, one H2D copy.  Subsequent `search` calls scan it; `add_embedding` appends.
-        Returns the number of rows."""
+        matrix: no per-crop dict entries, one H2D copy.  Subsequent `search` calls scan it; `add_embedding` appends (the
+        matrix grows as needed).  Returns the number of rows."""
         from .store import load_all
         paths, rows = load_all(self.base_path, 768)
-        if self._index is not None:
-            self._index.close()
-        dim = rows.shape[1] if len(paths) else 768
-        self._index = EmbeddingIndex(dim, max(capacity or 0, 2 * len(paths), 1024), device=self.model.device if self.model else 0)
+        index = EmbeddingIndex(768, max(capacity or 0, 2 * len(paths), 1024), device=self.model.device if self.model else 0,
+                               storage=self.index_storage)
+        table = _RowTable()
         if len(paths):
-            self._index.add(rows)
-        self._index_paths, self._index_src, self._attached = list(paths), "store", True
+            index.add(rows, table.extend(list(paths)))
+        self._replace("store", index, table)
+        self._attached = True
         return len(paths)
 
     def add_embedding(self, path: str, emb) -> None:
@@ -340,56 +477,92 @@ class ObjectFinder:
         the crop's day folder, in the dict the reference exposes, and in the attached device matrix."""
         from .store import EmbeddingStore
         e = np.asarray(as_numpy(emb), np.float32).reshape(1, -1)
-        EmbeddingStore(os.path.dirname(path), e.shape[1]).append([path], e)
+        if e.shape[1] != 768:
+            raise ValueError(f"expected a 768-d crop embedding, got {e.shape[1]}")
+        folder = os.path.dirname(path)
+        st = self._stores.get(folder)
+        if st is None:
+            st = self._stores[folder] = EmbeddingStore(folder, 768)
+        st.append([path], e)
         self.image_embeddings[path] = e
+        self._version["image"] += 1
         if getattr(self, "_attached", False):
-            self._index.add(e)
-            self._index_paths.append(path)
+            index, table = self._dev["store"]
+            index.add(e, table.extend([path]))
 
-    def _device_index(self, embeddings: Dict[str, np.ndarray]) -> EmbeddingIndex:
-        """(Re)build the HBM-resident matrix when the dict changed (the reference reloads before every search)."""
-        sig = (id(embeddings), len(embeddings))
-        if self._index is None or self._index_src != sig:
-            if self._index is not None:
-                self._index.close()
+    def _device_index(self, embeddings: Dict[str, np.ndarray], key: str = "image") -> Tuple[EmbeddingIndex, "_RowTable"]:
+        """(Re)build the HBM-resident matrix of one of the reference's dicts when it changed (the reference reloads before
+        every search; `_load_all_embeddings` / `add_embedding` bump the version when they change anything)."""
+        sig = (id(embeddings), len(embeddings), self._version[key])
+        if key not in self._dev or self._dev_sig.get(key) != sig:
             paths = [p for p, e in embeddings.items() if e is not None]
-            dim = np.asarray(embeddings[paths[0]]).size if paths else 768
-            self._index = EmbeddingIndex(dim, max(len(paths), 1), device=self.model.device if self.model else 0)
+            dim = int(np.asarray(embeddings[paths[0]]).size) if paths else (512 if key == "face" else 768)
+            index, table = self._new_index(dim, len(paths)), _RowTable()
             if paths:
-                self._index.add(np.stack([np.asarray(embeddings[p], np.float32).reshape(-1) for p in paths]))
-            self._index_paths, self._index_src = paths, sig
-        return self._index
+                index.add(np.stack([np.asarray(embeddings[p], np.float32).reshape(-1) for p in paths]), table.extend(paths))
+            self._replace(key, index, table)
+            self._dev_sig[key] = sig
+        return self._dev[key]
 
     # -- search (:356-390) ------------------------------------------------------------------------------
+    @staticmethod
+    def _rank(table: "_RowTable", rows, scores, grouped: bool):
+        """The tail of the reference's search (:378-390) over candidate rows given in ascending row order (= the dict's
+        iteration order): best crop per track id, id-less crops appended, stable sort by score."""
+        if grouped:
+            best, loose = {}, []
+            for r, sc in zip(rows, scores):
+                oid = table.oid[r]
+                if oid >= 0:
+                    if oid not in best or sc > best[oid][1]:
+                        best[oid] = (table.paths[r], sc)
+                else:
+                    loose.append((table.paths[r], sc))
+            results = list(best.values()) + loose
+        else:
+            results = [(table.paths[r], sc) for r, sc in zip(rows, scores)]
+        results.sort(key=lambda x: x[1], reverse=True)
+        return results
+
     def search(self, query=None, top_k=10, cam_name=None, timestamp=None, text_embedding=None, is_face=False):
         embeddings = self.face_embeddings if is_face else self.image_embeddings
-        attached = getattr(self, "_attached", False) and not is_face and len(self._index_paths) > 0
+        attached = getattr(self, "_attached", False) and not is_face and len(self._dev["store"][1].paths) > 0
         if not embeddings and not attached:
             print("No embeddings available.")
             return []
         if text_embedding is None:
             text_embedding = self.model._encode_text(query).numpy()
         q = np.asarray(as_numpy(text_embedding), np.float32).reshape(-1)
-        index = self._index if attached else self._device_index(embeddings)
-        scores = index.scores(q)[0]                         # one HBM pass instead of a Python loop of N dot products
-        sims = []
-        for path, sim in zip(self._index_paths, scores):
-            norm = path.replace("\\", "/")
-            if cam_name and f"/cameras/{cam_name}/" not in norm:
-                continue
-            if timestamp and f"/objects/{timestamp}/" not in norm and "/objects/video/" not in norm:
-                continue
-            fn = os.path.basename(path)
-            if fn.lower().endswith(".jpg"):
-                oid = event_img_info(fn.split(".jpg")[0])["object_id"] if "_" in fn else None
-                sims.append((path, float(sim), oid))
-        if any(s[2] for s in sims):
-            best = {}
-            for path, score, oid in sims:
-                if oid is not None and (oid not in best or score > best[oid][1]):
-                    best[oid] = (path, score)
-            results = list(best.values()) + [(p, s) for p, s, o in sims if o is None]
-        else:
-            results = [(p, s) for p, s, _ in sims]
-        results.sort(key=lambda x: x[1], reverse=True)
-        return results[:top_k]
+        index, table = self._dev["store"] if attached else self._device_index(embeddings, "face" if is_face else "image")
+        if q.size != index.dim:
+            raise ValueError(f"query has {q.size} dimensions, the {'face' if is_face else 'crop'} index {index.dim}")
+        allowed = table.allowed(cam_name, timestamp)
+        live = np.flatnonzero(allowed)
+        if live.size == 0 or top_k <= 0:
+            return []
+        exact_loop = any(table.bad[g] for g in live)
+        grouped = any(table.truthy[g] for g in live)
+        # GPU: filtered top-K' (one HBM pass + radix select); host: the reference's best-per-track-id tail on K' rows.
+        # The answer is exact once the top_k-th result scores strictly above the weakest candidate (no unseen row can
+        # enter or change it) or every allowed row has been seen; otherwise K' grows, and past 1024 the full score vector
+        # is ranked (many crops of few tracks above everything else: rare).
+        kk = min(1024, max(128, 16 * int(top_k)))
+        while not exact_loop:
+            idx, sc = index.search(q, kk, allowed)
+            keep = idx[0] >= 0
+            rows, scs = idx[0][keep], sc[0][keep]
+            order = np.argsort(rows, kind="stable")
+            results = self._rank(table, rows[order].tolist(), [float(v) for v in scs[order]], grouped)
+            if rows.size < kk or (len(results) >= top_k and results[top_k - 1][1] > float(scs.min())):
+                return results[:top_k]
+            if kk == 1024:
+                break
+            kk = min(1024, kk * 4)
+        scores = index.scores(q)[0]                         # the whole score vector, ranked like the reference does it
+        rows = [r for r in range(len(table.paths)) if allowed[table.group[r]]]
+        if exact_loop:                                      # names the reference itself would raise on: let it raise the same way
+            for r in rows:
+                fn = os.path.basename(table.paths[r])
+                if "_" in fn:
+                    event_img_info(fn.split(".jpg")[0])
+        return self._rank(table, rows, [float(scores[r]) for r in rows], grouped)[:top_k]

@@ -7,7 +7,7 @@ unpickles every folder again before every search (models/objects.py:392-422, cal
 Here a folder holds two append-only files:
   embeddings.f32   N x dim float32 rows, no header      -> np.memmap, handed to cc_index_add as is (one H2D copy)
   embeddings.idx   N lines, the crop path of each row (UTF-8, '\\n' separated)
-A crop costs one row + one line.  Rows are written before their index line, and a reader takes
+A crop costs one row + one line (the writer caches the consistent prefix and validates it with two stat calls).  Rows are written before their index line, and a reader takes
 N = min(complete rows, complete lines), so a crash between the two writes loses at most the last crop and never
 mis-pairs a path with a vector.  `import_pickle` / `as_reference_dict` convert from / to the reference's format, so
 existing data keeps working and the reference can still read what this store holds.
@@ -27,10 +27,28 @@ class EmbeddingStore:
     def __init__(self, folder: str, dim: int = 768):
         self.folder, self.dim = folder, dim
         self.data_path, self.index_path = os.path.join(folder, DATA), os.path.join(folder, INDEX)
+        self._n = self._idx_bytes = None                        # rows / index bytes of the consistent prefix, once known
 
     # -- write ------------------------------------------------------------------------------------------
-    def append(self, paths: Sequence[str], embs) -> int:
-        """Append len(paths) rows; embs (n,dim) or (n,1,dim) float32.  Returns the new row count."""
+    def _sizes(self) -> Tuple[int, int]:
+        return (os.path.getsize(self.data_path) if os.path.exists(self.data_path) else 0,
+                os.path.getsize(self.index_path) if os.path.exists(self.index_path) else 0)
+
+    def _state(self) -> Tuple[int, int]:
+        """(rows, index bytes) of the consistent prefix.  The index file is read in full only when the cached state no
+        longer matches the file sizes (first use, another writer, a torn write): an append costs two stat calls, one row
+        and one line — not a re-read of the whole folder."""
+        if self._n is not None and self._sizes() == (self._n * self.dim * 4, self._idx_bytes):
+            return self._n, self._idx_bytes
+        lines = self._lines()
+        rows = self._sizes()[0] // (self.dim * 4)
+        n = min(rows, len(lines))
+        self._n, self._idx_bytes = n, sum(len(p.encode("utf-8")) + 1 for p in lines[:n])
+        return self._n, self._idx_bytes
+
+    def append(self, paths: Sequence[str], embs, durable: bool = True) -> int:
+        """Append len(paths) rows; embs (n,dim) or (n,1,dim) float32.  Returns the new row count.  durable=False skips the
+        two fsyncs (the pairing guarantee needs only the order rows-then-lines; fsync adds power-loss durability)."""
         e = np.ascontiguousarray(np.asarray(embs, np.float32).reshape(len(paths), -1))
         if e.shape[1] != self.dim:
             raise ValueError(f"expected {self.dim}-d embeddings, got {e.shape[1]}")
@@ -38,18 +56,24 @@ class EmbeddingStore:
             if "\n" in p:
                 raise ValueError("newline in path")
         os.makedirs(self.folder, exist_ok=True)
-        n = len(self)                                           # also the recovery point after a torn write
+        n, ib = self._state()                                   # also the recovery point after a torn write
+        text = "".join(p + "\n" for p in paths).encode("utf-8")
         with open(self.data_path, "r+b" if os.path.exists(self.data_path) else "wb") as f:
             f.seek(n * self.dim * 4)
             f.truncate()
             f.write(e.tobytes())
-            f.flush(); os.fsync(f.fileno())
+            f.flush()
+            if durable:
+                os.fsync(f.fileno())
         with open(self.index_path, "r+b" if os.path.exists(self.index_path) else "wb") as f:
-            f.seek(self._index_bytes(n))
+            f.seek(ib)
             f.truncate()
-            f.write("".join(p + "\n" for p in paths).encode("utf-8"))
-            f.flush(); os.fsync(f.fileno())
-        return n + len(paths)
+            f.write(text)
+            f.flush()
+            if durable:
+                os.fsync(f.fileno())
+        self._n, self._idx_bytes = n + len(paths), ib + len(text)
+        return self._n
 
     # -- read -------------------------------------------------------------------------------------------
     def _lines(self) -> List[str]:
@@ -59,12 +83,8 @@ class EmbeddingStore:
         end = raw.rfind(b"\n") + 1                              # drop an incomplete last line
         return raw[:end].decode("utf-8").split("\n")[:-1] if end else []
 
-    def _index_bytes(self, n: int) -> int:
-        return sum(len(p.encode("utf-8")) + 1 for p in self._lines()[:n])
-
     def __len__(self) -> int:
-        rows = os.path.getsize(self.data_path) // (self.dim * 4) if os.path.exists(self.data_path) else 0
-        return min(rows, len(self._lines()))
+        return self._state()[0]
 
     def paths(self) -> List[str]:
         return self._lines()[:len(self)]

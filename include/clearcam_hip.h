@@ -160,12 +160,24 @@ void cc_ocsort_destroy(cc_ocsort* h);
  * Path filtering / best-per-track-id / sorting of the reference stay in the Python shim.
  * ------------------------------------------------------------------------------------------- */
 typedef struct cc_index cc_index;
-int cc_index_create(cc_index** h, int dim, int64_t capacity, int device);
-int cc_index_add(cc_index* h, const float* emb, int64_t n, int on_device);       /* append n rows (n,dim) f32 */
+int cc_index_create(cc_index** h, int dim, int64_t capacity, int device);        /* f32 rows */
+/* storage 0: f32 rows, exact f32 dot products.  storage 2: rows rounded to bf16 (half the bytes per scan; scores within
+ * ~1e-3 of the f32 index for unit vectors; dim % 256 == 0).  `capacity` is the initial allocation: the matrix grows
+ * geometrically (device-to-device copy) when cc_index_add* runs past it. */
+int cc_index_create_ex(cc_index** h, int dim, int64_t capacity, int device, int storage);
+int cc_index_add(cc_index* h, const float* emb, int64_t n, int on_device);       /* append n rows (n,dim) f32, group 0 */
+/* the same with one group id (0 <= id < 2^24) per row on the HOST: the caller's (camera, day folder) bucket, the unit
+ * `ObjectFinder.search` filters by (models/objects.py:368-371: `/cameras/<cam>/`, `/objects/<day>/` substrings) */
+int cc_index_add_grouped(cc_index* h, const float* emb, int64_t n, int on_device, const int32_t* groups);
 int cc_index_size(cc_index* h, int64_t* n);
+int cc_index_info(cc_index* h, int64_t* capacity, int* storage, int* dim);       /* any pointer may be NULL */
 int cc_index_scores(cc_index* h, const float* q, int Q, float* scores, int on_device, void* stream); /* (Q,N) */
 /* top-k per query by score (ties: lower row id first): idx (Q,k) int32, score (Q,k) f32; rows past N: -1/-inf */
 int cc_index_search(cc_index* h, const float* q, int Q, int k, int32_t* idx, float* score, int on_device, void* stream);
+/* top-k restricted to rows whose group is allowed: `allowed` = n_groups bytes on the HOST (non-zero keeps the group),
+ * NULL = no filter; fewer than k allowed rows -> -1/-inf padding */
+int cc_index_search_groups(cc_index* h, const float* q, int Q, int k, const uint8_t* allowed, int n_groups, int32_t* idx, float* score,
+                           int on_device, void* stream);
 void cc_index_destroy(cc_index* h);
 
 #ifdef __cplusplus
