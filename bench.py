@@ -9,6 +9,9 @@ over one batch of 64 synthetic 640x640 BGR uint8 frames that are already residen
 cameras shard one-per-GPU, there is no data-path collective for detection — and
 value = all ranks' frames / max-over-ranks time ("weak" scaling).
 
+Environment (tests only): CLEARCAM_BENCH_BACKEND=gloo runs the N>1 plumbing on CPU tensors with whatever model classes
+the caller has put in place (tests/test_bench_multi.py mocks them); the default is "nccl" (RCCL) on cuda:LOCAL_RANK.
+
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      dominant kernel family (conv_mfma_kernel): algorithmic FLOPs per step / its summed
                 duration per step, measured live with hipEvents on the launch stream (cc_yolo_profile)
@@ -53,7 +56,8 @@ def cpu_baseline(size: str, res: int, seconds: float = 15.0) -> dict:
         o(frame)
         n += 1
     dt = time.time() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+            "host_cores_usable": avail, "kind": "port",
             "sample": f"{n} frames of {res}x{res}, batch 1 (reference semantics), PyTorch-CPU fp32 restatement "
                       f"of detection/yolov9.py (tinygrad CPU path not runnable offline)"}
 
@@ -67,22 +71,28 @@ def clip_side_metrics(device_index: int, dev) -> dict:
     from clearcam_amd.weights import synthetic_clip_state_dict
     out = {}
     m = OpenCLIP(state_dict=synthetic_clip_state_dict(CLIP_L14, 4321), arch=CLIP_L14, dtype="bf16", device=device_index)
+
+    def rate(B, reps):
+        x = torch.rand(B, 3, 224, 224, device=dev) * 2 - 1
+        emb = torch.empty(B, 768, device=dev)
+        for _ in range(2):
+            m.precompute_embedding_device(x, emb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.precompute_embedding_device(x, emb)
+        torch.cuda.synchronize()
+        return B / ((time.perf_counter() - t0) / reps)
     B = 255                                      # 255 images x 257 tokens = 65535 rows: whole rounds of 256-row GEMM tiles on 256 CUs
-    x = torch.rand(B, 3, 224, 224, device=dev) * 2 - 1
-    emb = torch.empty(B, 768, device=dev)
-    for _ in range(2):
-        m.precompute_embedding_device(x, emb)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 4
-    for _ in range(n):
-        m.precompute_embedding_device(x, emb)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    out["image_embeds_per_sec"] = round(B / dt, 1)
+    r = rate(B, 4)
+    out["model"] = "ViT-L/14 (the model the reference runs, models/objects.py:29-89)"
+    out["image_embeds_per_sec"] = round(r, 1)
     out["image_batch"] = B
-    out["image_tflops"] = round(B * 162.03e9 / dt / 1e12, 1)
-    out["seconds_per_10k_crops"] = round(10000 / (B / dt), 3)
+    out["image_tflops"] = round(r * 162.03e9 / 1e12, 1)
+    out["image_frac_of_mfma_peak"] = round(r * 162.03e9 / 1e12 / PEAK_TFLOPS["bf16"], 4)
+    out["seconds_per_10k_crops"] = round(10000 / r, 3)
+    # the reference's own speed test sweeps the batch size (test/test_clip_speed.py:8-15: bs = 1, 2, 4, ... 128)
+    out["image_embeds_per_sec_by_batch"] = {str(b): round(rate(b, 8 if b <= 16 else 4), 1) for b in (1, 2, 4, 8, 16, 32, 64, 128)}
     toks = np.zeros((64, 77), np.int32)
     toks[:, 0] = 49406
     toks[:, 1:5] = [9606, 325, 275, 271]
@@ -92,7 +102,7 @@ def clip_side_metrics(device_index: int, dev) -> dict:
     m.encode_tokens(toks)
     out["text_embeds_per_sec"] = round(64 / (time.perf_counter() - t0), 1)
     m.close()
-    # ViT-B/32, the model the north star names (the reference code itself runs ViT-L/14): same engine, 50 tokens per image
+    # ViT-B/32 (named in BASELINE.json's north star; NOT the model the reference runs and not the 10k-crops target): same engine
     from clearcam_amd.arch import CLIP_B32
     mb = OpenCLIP(state_dict=synthetic_clip_state_dict(CLIP_B32, 99), arch=CLIP_B32, dtype="bf16", device=device_index)
     Bb = 1024
@@ -132,41 +142,35 @@ def clip_side_metrics(device_index: int, dev) -> dict:
         bz(img)
     out["blazeface_ms_per_image"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)     # batch 1, as the reference calls it
     bz.close()
-    # search: 125k x 768 f32 shard (1 M vectors over 8 GPUs), k=100, 1 query; HBM-bound scan of 384 MB
-    N = 125_000
-    ix = EmbeddingIndex(768, N, device=device_index)
-    e = torch.randn(N, 768, device=dev)
-    e /= e.norm(dim=1, keepdim=True)
-    ix.add(e)
-    q = torch.randn(1, 768)
-    q /= q.norm()
-    qn = q.numpy()
-    for _ in range(3):
-        ix.search(qn, 100)
-    lat = []
-    for _ in range(200):
-        t0 = time.perf_counter()
-        ix.search(qn, 100)
-        lat.append(time.perf_counter() - t0)
-    lat.sort()
-    out["search_125k_k100_p50_ms"] = round(lat[len(lat) // 2] * 1e3, 3)
-    out["search_125k_k100_p99_ms"] = round(lat[int(len(lat) * 0.99)] * 1e3, 3)
-    # host-observed: query upload + scan + two top-k kernels + result read-back; the scan kernel alone runs at ~6.1 TB/s
-    # (63 us per pass, profiles/), so this end-to-end figure is the call's floor of N*dim*4 bytes over its whole latency
-    out["search_end_to_end_GBps"] = round(N * 768 * 4 / lat[len(lat) // 2] / 1e9, 1)
-    q64 = torch.randn(64, 768)
-    q64 /= q64.norm(dim=1, keepdim=True)
-    q64 = q64.numpy()
-    for _ in range(3):
-        ix.search(q64, 100)
-    lat = []
-    for _ in range(10):
-        t0 = time.perf_counter()
-        ix.search(q64, 100)
-        lat.append(time.perf_counter() - t0)
-    lat.sort()
-    out["search_125k_k100_64queries_p50_ms"] = round(lat[len(lat) // 2] * 1e3, 3)   # one GEMM pass over the shard for all 64
-    ix.close()
+    # search (BASELINE.json configs[4]): k=100, 1 and 64 queries, host-observed call latency (query upload + scan + top-k +
+    # result read-back).  125 k rows = one GPU's shard of 1 M vectors over 8 GPUs; 1 M rows = the whole index on ONE GPU
+    # (3.07 GB f32 / 1.54 GB bf16: HBM-bound scans).  bf16 rows change scores by <= 1e-3 (tests/test_gpu_clip.py).
+    def search_case(N, storage):
+        ix = EmbeddingIndex(768, N, device=device_index, storage=storage)
+        g = torch.Generator(device=dev).manual_seed(3)
+        for i in range(0, N, 125_000):
+            e = torch.randn(min(125_000, N - i), 768, device=dev, generator=g)
+            e /= e.norm(dim=1, keepdim=True)
+            ix.add(e)
+        res = {"rows": N, "storage": storage, "k": 100}
+        for Q, reps in ((1, 200), (64, 20)):
+            q = torch.randn(Q, 768, generator=torch.Generator().manual_seed(7))
+            q = (q / q.norm(dim=1, keepdim=True)).numpy()
+            for _ in range(3):
+                ix.search(q, 100)
+            lat = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                ix.search(q, 100)
+                lat.append(time.perf_counter() - t0)
+            lat.sort()
+            res[f"q{Q}_p50_ms"] = round(lat[len(lat) // 2] * 1e3, 3)
+            res[f"q{Q}_p99_ms"] = round(lat[min(len(lat) - 1, int(len(lat) * 0.99))] * 1e3, 3)
+        res["q1_end_to_end_GBps"] = round(N * 768 * (4 if storage == "f32" else 2) / (res["q1_p50_ms"] * 1e-3) / 1e9, 1)
+        ix.close()
+        return res
+    out["search"] = {"shard_125k_f32": search_case(125_000, "f32"), "one_gpu_1M_f32": search_case(1_000_000, "f32"),
+                     "one_gpu_1M_bf16": search_case(1_000_000, "bf16")}
     return out
 
 
@@ -178,12 +182,22 @@ def sharded_search_metrics(device_index: int, dev, world: int, rank: int) -> dic
     import torch.distributed as dist
     from clearcam_amd.dist import ShardedIndex
     from clearcam_amd.objects import EmbeddingIndex
-    N = 125_000
-    ix = EmbeddingIndex(768, N, device=device_index)
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
-    e = torch.randn(N, 768, device=dev, generator=g)
-    e /= e.norm(dim=1, keepdim=True)
-    ix.add(e)
+    N = int(os.environ.get("CLEARCAM_BENCH_SHARD_ROWS", 125_000))
+    ix, err = None, ""
+    try:                                         # local set-up may fail on one rank (memory): agree before any collective
+        ix = EmbeddingIndex(768, N, device=device_index)
+        g = torch.Generator(device=dev).manual_seed(100 + rank)
+        e = torch.randn(N, 768, device=dev, generator=g)
+        e /= e.norm(dim=1, keepdim=True)
+        ix.add(e)
+    except Exception as exc:                     # noqa: BLE001
+        err = f"{type(exc).__name__}: {exc}"
+    ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 1.0:
+        if ix is not None:
+            ix.close()
+        return {"error": err or "another rank failed to build its shard"}
     sh = ShardedIndex(ix, device=dev)
     q = torch.randn(1, 768, generator=torch.Generator().manual_seed(7))
     q /= q.norm()
@@ -191,8 +205,7 @@ def sharded_search_metrics(device_index: int, dev, world: int, rank: int) -> dic
     for _ in range(3):
         ids, sc = sh.search(qn, 100)
     lat = []
-    for _ in range(20):
-        dist.barrier()
+    for _ in range(20):                          # the all-gather inside every search keeps the ranks in step
         t0 = time.perf_counter()
         ids, sc = sh.search(qn, 100)
         lat.append(time.perf_counter() - t0)
@@ -202,7 +215,8 @@ def sharded_search_metrics(device_index: int, dev, world: int, rank: int) -> dic
     ok = bool((np.diff(sc[0]) <= 0).all() and (ids[0] >= 0).all() and ids[0].max() < sh.total)
     ix.close()
     return {"rows_total": int(sh.total), "rows_per_gpu": N, "k": 100, "p50_ms": round(float(t[0]) * 1e3, 3),
-            "max_ms": round(float(t[1]) * 1e3, 3), "exchange_bytes_per_rank": 100 * 16, "result_sorted_and_in_range": ok}
+            "max_ms": round(float(t[1]) * 1e3, 3), "exchange_bytes_per_rank": 100 * 16, "result_sorted_and_in_range": ok,
+            "exchange": "device-resident: scan + top-k, one all-gather of (1,2,100) int64 per rank, merge on the GPU, one copy out"}
 
 
 def stream_side_metrics(device_index: int, size: str, res: int, dtype: str) -> dict:
@@ -227,6 +241,33 @@ def stream_side_metrics(device_index: int, size: str, res: int, dtype: str) -> d
     return out
 
 
+def kernel_source_digest() -> str:
+    """sha256[:16] over clearcam_amd/csrc/*: ties a PMC measurement under profiles/ to the kernels it was taken from."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "clearcam_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(default_cfg: bool):
+    """HBM bytes per step of the conv kernels from this round's rocprofv3 PMC passes (profiles/pmc_traffic.json, written
+    by tools/pmc_traffic.py on the GPU box).  A file taken from other kernels than the ones in the tree is NOT quoted."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    if not default_cfg:
+        return None, "PMC traffic is recorded for the headline configuration only"
+    if not os.path.exists(path):
+        return None, "profiles/pmc_traffic.json missing: run tools/pmc_traffic.py on the GPU box"
+    rec = json.load(open(path))
+    if rec.get("kernel_source_digest") != kernel_source_digest():
+        print(f"bench: profiles/pmc_traffic.json was measured on other kernels ({rec.get('kernel_source_digest')} != "
+              f"{kernel_source_digest()}); roofline.traffic left null — re-run tools/pmc_traffic.py", file=sys.stderr)
+        return None, "stale: kernels changed since the PMC passes in profiles/pmc_traffic.json; re-run tools/pmc_traffic.py"
+    return float(rec["conv_bytes_per_step"]), rec.get("note", "")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +282,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clip", action="store_true", help="skip the CLIP / search side metrics")
     ap.add_argument("--no-streams", action="store_true", help="skip the camera-pipeline side metrics (detect -> OC-SORT incl. PCIe)")
+    ap.add_argument("--no-precisions", action="store_true", help="skip the f16 / f32 throughput legs")
     args = ap.parse_args()
 
     import torch
@@ -251,13 +293,20 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("CLEARCAM_BENCH_BACKEND", "nccl")
+    on_gpu = backend == "nccl"
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if on_gpu:
+        torch.cuda.set_device(local)
 
     sd = synthetic_yolov9_state_dict(args.size, 1234)
     model = YOLOv9(args.size, args.res, state_dict=sd, dtype=args.dtype, device=local)
@@ -270,23 +319,52 @@ def main() -> None:
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        model.detect_batch_device(frames, out)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.detect_batch_device(frames, out)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(m, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            m.detect_batch_device(frames, out)
+        sync(); barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.detect_batch_device(frames, out)
+        sync(); barrier(); sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    elapsed = timed(model, args.steps, args.warmup)
     n_det = int((out[..., 4] > 0).sum().item())
+
+    # SURVEY.md 8(d): >= 100 timed iterations, median.  Per-step wall times on this rank (each step synchronised), next to
+    # the contract's K-step total above.
+    median_100 = None
+    if world == 1:
+        per = []
+        for _ in range(100):
+            sync(); t1 = time.perf_counter()
+            model.detect_batch_device(frames, out)
+            sync(); per.append(time.perf_counter() - t1)
+        per.sort()
+        median_100 = {"steps": 100, "ms_median": round(per[50] * 1e3, 3), "ms_p10": round(per[10] * 1e3, 3), "ms_p90": round(per[90] * 1e3, 3),
+                      "frames_per_sec_at_median": round(B / per[50], 1)}
+
+    # the other storage modes on the same workload (weights re-packed, same frames): the f32 parity mode is the one whose
+    # detections match the reference path to the north star's 1e-3; bf16 / f16 are held to the 16-bit bars (tests/)
+    precisions = None
+    if not args.no_precisions and world == 1:
+        precisions = {args.dtype: round(B * args.steps / elapsed, 1)}
+        for dt_name, steps in (("bf16", args.steps), ("f16", args.steps), ("f32", max(3, args.steps // 4))):
+            if dt_name in precisions:
+                continue
+            try:
+                m2 = YOLOv9(args.size, args.res, state_dict=sd, dtype=dt_name, device=local)
+                precisions[dt_name] = round(B * steps / timed(m2, steps, 2), 1)
+                m2.close()
+            except Exception as exc:             # noqa: BLE001  a side metric
+                precisions[dt_name] = f"error: {type(exc).__name__}: {exc}"
 
     streams_multi = None
     if world > 1 and not args.no_streams:
@@ -307,8 +385,8 @@ def main() -> None:
                 pipe.close(); m2.close(); del cams
             except Exception as exc:             # noqa: BLE001
                 err = f"{type(exc).__name__}: {exc}"
-        tot = stats.to(dev); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        neg = (-stats[:, 1]).to(dev); dist.all_reduce(neg, op=dist.ReduceOp.MAX)      # min over ranks of fps per camera
+        tot = stats.clone().to(dev); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        neg = (-stats[:, 1]).clone().to(dev); dist.all_reduce(neg, op=dist.ReduceOp.MAX)      # min over ranks of fps per camera
         streams_multi = {}
         for ci, n_cams in enumerate((8, 64)):
             streams_multi[f"cams{n_cams}_per_gpu"] = {"cameras_total": n_cams * world, "ranks_ok": int(tot[ci, 3].item()),
@@ -319,15 +397,21 @@ def main() -> None:
             streams_multi["error_rank0"] = err
     sharded = None
     if (world > 1 or os.environ.get("CLEARCAM_BENCH_FORCE_SHARDED")) and not args.no_clip:
-        model_was = model
         try:                                     # side metric: must never take the headline line down with it
             if world == 1 and not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+                if on_gpu:
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                else:
+                    dist.init_process_group(backend, rank=0, world_size=1)
             sharded = sharded_search_metrics(local, dev, world, rank)
         except Exception as exc:                 # noqa: BLE001
             sharded = {"error": f"{type(exc).__name__}: {exc}"}
-        model = model_was
+        # every rank reaches this point whatever happened above; agree on success so that no rank waits in a collective alone
+        if world > 1:
+            ok = torch.tensor([0.0 if "error" in sharded else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+            sharded["ranks_ok"] = int(ok.item())
     if rank == 0:
         fps = world * B * args.steps / elapsed
         import csv
@@ -353,9 +437,8 @@ def main() -> None:
         conv_s = prof["conv_ms"] * 1e-3
         achieved = alg_flops / conv_s / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        # PMC-measured HBM traffic of the conv kernels for the headline configuration only (counters cannot be read in-process)
         default_cfg = (args.size, args.res, B, args.dtype, fh, fw) == ("c", 640, 64, "bf16", 640, 640)
-        traffic = 25.11e9 if default_cfg else None
+        traffic, traffic_note = measured_traffic(default_cfg)
         line = {
             "metric": f"yolov9{args.size}_{args.res}x{args.res}_frames_per_sec" if (fh, fw) == (args.res, args.res)
                       else f"yolov9{args.size}_{fh}x{fw}_letterbox{args.res}_frames_per_sec",
@@ -367,15 +450,19 @@ def main() -> None:
                                    f"(letterbox+convs+decode+top300+NMS)",
                        "batch_per_gpu": B, "parallelism": f"one camera batch per GPU x{world}, no collective",
                        "detections_last_batch": n_det},
+            "parity": {"f32": "every oracle detection matched one-to-one (class, IoU >= 0.9), boxes within 1e-3 x max(H,W) px and scores within "
+                              "1e-3 - north_star's unitless 'box coords within 1e-3' read in image-normalised units (this repo's reading; "
+                              "1e-3 px absolute is below f32 round-off of a 144-conv network); measured 0.03-0.17 px",
+                       "bf16_f16": "well-conditioned synthetic checkpoint (perturbation gain ~1, bf16-exact weights) at this batch and size: >= 95 % "
+                                   "one-to-one matches at IoU >= 0.9, per-anchor scores within 1e-2, P3/P4/P5 rel-RMS <= 3e-2 (bf16) / 4e-3 (f16); "
+                                   "measured bf16 96.3 %, f16 99.6 % (tests/test_gpu_yolo.py, __graft_entry__.smoke)",
+                       "frames_per_sec_by_storage_dtype": precisions},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          # the bandwidth-side fraction, unfused activation traffic (380.6 MB/frame bf16 at 640x640) over 8 TB/s
                          "hbm_side_frac": round(fps / world * 380.6e6 / 8e12, 4) if (fh, fw, args.res, args.size) == (640, 640, 640, "c") else None,
-                         "traffic": traffic,
-                         "traffic_note": "HBM bytes per step of the conv kernels from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                         "(profiles/r01e_yolo_bf16_b64.txt, FETCH x2 per the gfx950 correction); not re-measured in this run"
-                                         if traffic else None,
-                         "kernel": "conv kernels: conv_mfma_kernel (all instantiations) + conv_big_kernel + conv3x3_halo_kernel + conv3x3_ws_kernel (the fused letterbox + first conv is reported under other_ms_per_step)",
+                         "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": "conv kernels (every conv launch of the plan; the fused letterbox + first conv is reported under other_ms_per_step)",
                          "alg_gflop_per_step": round(alg_flops / 1e9, 2), "kernel_ms_per_step": round(prof["conv_ms"], 3),
                          "launches_per_step": prof["conv_launches"], "heaviest_launch": heaviest,
                          "other_ms_per_step": {k: round(prof[k], 3) for k in ("pool_ms", "decode_ms", "nms_ms", "stem_ms")},
@@ -383,6 +470,8 @@ def main() -> None:
                                  "kernel): its time and its 0.35 % of the FLOPs are outside achieved/frac" if prof.get("stem_ms") else None},
             "gflop_per_frame": round((alg_flops + stem_flops) / B / 1e9, 2),
         }
+        if median_100:
+            line["median_100_steps"] = median_100
         # BASELINE.json configs[0] shape of call: one frame per call (the reference's batch-1 semantics), device-resident frame,
         # call-to-result latency including the (300,6) read-back
         try:
@@ -401,7 +490,7 @@ def main() -> None:
         model.close()
         if not args.no_streams and world == 1:
             line["streams"] = stream_side_metrics(local, args.size, args.res, args.dtype)
-        if not args.no_clip:
+        if not args.no_clip and on_gpu:
             line["clip"] = clip_side_metrics(local, dev)
         if streams_multi is not None:
             line["streams_multi_gpu"] = streams_multi
