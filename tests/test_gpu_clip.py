@@ -105,8 +105,10 @@ def test_index_scores_and_topk_exact():
     small = EmbeddingIndex(768, 10); small.add(E[:3])
     i3, s3 = small.search(q[:1], 5)
     assert (i3[0, 3:] == -1).all() and sorted(i3[0, :3].tolist()) == [0, 1, 2]
-    with pytest.raises(Exception):
-        small.add(E[:100])                                                # capacity exceeded -> error, not truncation
+    small.add(E[:100])                                                    # past the initial capacity: the matrix grows, nothing is lost
+    assert len(small) == 103 and small.capacity >= 103
+    i4, _ = small.search(E[50:51], 1)
+    assert i4[0, 0] in (50, 53)                                           # E[50] is stored as rows 50 and 53 (ties -> the lower row id)
 
 
 def test_object_finder_search_matches_reference_loop(tiny):
