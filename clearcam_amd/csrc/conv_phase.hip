@@ -1,0 +1,266 @@
+// The eight-wave, two-group ("ping-pong") 256 x 256 implicit-GEMM kernel: its own translation unit (compile time).
+#include "conv_tile.h"
+
+namespace cc {
+
+// ---- 256 x 256 tile, EIGHT waves in two groups that alternate an LDS/DMA segment and an MFMA segment -----------------------
+// The four-wave kernel above leaves one wave per SIMD: whenever that wave reads LDS, issues DMA or waits at its barrier the
+// SIMD's matrix pipe idles.  Here two waves share each SIMD (waves w and w+4) and run half a phase apart, so that while one
+// reads the operands of its next quadrant and issues DMA, the other issues 16 MFMAs with raised priority (the 8-phase schedule
+// of cdna_hip_programming.md §5, re-derived for this loader).  A wave owns 128 pixels x 64 channels (32 accumulator fragments);
+// a K tile (64 halfs) is four phases, one accumulator quadrant (64 pixels x 32 channels x K 64 = 16 MFMAs) each:
+//     phase 1  read W-subtile 0 + P-subtile 0 | DMA | barrier | MFMA (P0,W0) | barrier
+//     phase 2  read W-subtile 1               | DMA | barrier | MFMA (P0,W1) | barrier
+//     phase 3  read P-subtile 1               | DMA | barrier | MFMA (P1,W1) | barrier
+//     phase 4  read W-subtile 0 again          | DMA | vmcnt | barrier | MFMA (P1,W0) | barrier   (one W buffer: registers)
+// LDS holds two K tiles (2 x 64 KB); each is four half-tiles of 128 rows (pixel rows 0-127 / 128-255, weight rows likewise),
+// 2 DMA instructions per thread each, ONE half-tile issued per phase into a slot whose last reader finished at least one full
+// phase earlier: with E / O the even / odd tile in LDS and E' / O' the tiles two steps ahead
+//     phase of tile t:   1           2           3           4
+//     issue:             P1(t+1)     W0(t+1)     W1(t+1)     P0(t+2)
+//     wait:                                                  vmcnt(2): tile t+1 landed
+// pixel pieces (HBM / far L2) have four to five phases to land, weight pieces (L2 hits) one to two, and the queue is never
+// drained in the main loop.  Every wave's ds_reads are retired
+// (lgkmcnt(0)) BEFORE the barrier that ends its read segment, which is what allows a slot to be re-used one phase later.
+template <class T>
+__global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const ConvAux a) {
+  constexpr int BM = 256, BN = 256, NT = 512, MI = 8, NJ = 4;
+  constexpr int E = 8, CPRW = 8, BK = 64, RPP = NT / CPRW, XR = BM / RPP, WR = BN / RPP;   // 64 rows per pass, 4 passes per operand
+  constexpr int STAGE = (BM + BN) * CPRW;              // uint4 per K tile
+  static_assert(sizeof(T) == 2 && XR == 4 && WR == 4, "16-bit storage, four DMA passes per operand");
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;            // pixel half (= ping-pong group) / channel quarter
+  const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
+  const unsigned lds_base = lds_addr(lds);
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt_ = wg / a.nt;
+  const int m0 = mt_ * BM, n0 = (wg - mt_ * a.nt) * BN;
+
+  // ---- loader state: pixel rows prow + 64 i with per-row pointers (halo taps -> zero page), weight rows from one pointer ------
+  const int ppos = tid % CPRW, prow = tid / CPRW;
+  const int chunk = ppos ^ swz<CPRW>(prow);            // swz(prow + 64 i) is the same for every i
+  // Per pixel row: the byte address of (its window's top-left pixel, channel coff) and the 9-bit tap-validity mask.  They are
+  // only needed when the K walk crosses into the next filter tap (every Cin/64 tiles), so they live in the 24 KB of LDS behind
+  // the two K-tile stages instead of in 12 VGPRs that the accumulators need.
+  struct RowInfo { const char* ptr; unsigned mask; unsigned pad; };
+  RowInfo* rinfo = reinterpret_cast<RowInfo*>(lds + 2 * STAGE) + tid * XR;
+  const char* cur[XR]; unsigned inc[XR];
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    const int m = m0 + prow + RPP * i;
+    RowInfo ri;
+    if (a.is1x1) {
+      ri.ptr = reinterpret_cast<const char*>(p.s0.ptr) + ((size_t)m * p.s0.cstride + p.s0.coff) * sizeof(T);
+      ri.mask = m < M ? 1u : 0u;
+    } else {
+      const int mm = m < M ? m : 0;
+      const int b = fdiv(mm, hw, a.inv_hw), rem = mm - b * hw, ho = fdiv(rem, p.Wo, a.inv_wo), wo = rem - ho * p.Wo;
+      const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+      unsigned hm = 0, wmk = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        hm |= (unsigned)(r < p.ks && (unsigned)(h0 + r) < (unsigned)p.Hin) << r;
+        wmk |= (unsigned)(r < p.ks && (unsigned)(w0 + r) < (unsigned)p.Win) << r;
+      }
+      const unsigned vm = ((hm & 1u) ? wmk : 0u) | ((hm & 2u) ? wmk << p.ks : 0u) | ((hm & 4u) ? wmk << (2 * p.ks) : 0u);
+      ri.mask = m < M ? vm : 0u;
+      ri.ptr = reinterpret_cast<const char*>(p.s0.ptr) +
+               ((((long)b * p.s0.H + h0) * p.s0.W + w0) * (long)p.s0.cstride + p.s0.coff) * (long)sizeof(T);
+    }
+    ri.pad = 0;
+    rinfo[i] = ri;
+  }
+  // weights: Cout is a multiple of 256 here, every row exists; row n0 + prow + 64 i, advancing BK halfs per K tile
+  const char* wptr = reinterpret_cast<const char*>(p.w) + ((size_t)(n0 + prow) * p.Kw + chunk * E) * sizeof(T);
+  const size_t wpass = (size_t)RPP * p.Kw * sizeof(T);
+  // K walk: Cin is a multiple of 64 (checked on the host), so a K tile never straddles two filter taps and every thread
+  // changes tap at the same tile
+  int kc = 0, tap = 0;                                 // channel offset of the current tile inside its tap; tap index r * ks + s
+  auto retarget = [&]() {
+    const int kr = tap / p.ks, ks_ = tap - kr * p.ks;
+    const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc + chunk * E) * (long)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const RowInfo ri = rinfo[i];
+      const bool ok = (ri.mask >> tap) & 1u;
+      cur[i] = ok ? ri.ptr + delta : reinterpret_cast<const char*>(&g_zero16);
+      inc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
+    }
+  };
+  retarget();
+  auto advance_p = [&]() {
+    kc += BK;
+    if (kc == p.Cin) { kc = 0; ++tap; retarget(); }
+    else {
+#pragma unroll
+      for (int i = 0; i < XR; ++i) cur[i] += inc[i];
+    }
+  };
+  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * 64) * 16u);
+  // half-tile h of the pixels / weights of a K tile -> passes 2h, 2h+1 of that operand's slab in `stage`
+  auto issue_p = [&](unsigned stage_bytes, int h) {
+    const unsigned sb = wave_lds + stage_bytes;
+    glds16_m0(cur[2 * h], sb + (2 * h) * (NT * 16u));
+    glds16_m0(cur[2 * h + 1], sb + (2 * h + 1) * (NT * 16u));
+  };
+  auto issue_w = [&](unsigned stage_bytes, int h) {
+    const unsigned sb = wave_lds + stage_bytes + (unsigned)(BM * CPRW) * 16u;
+    glds16_m0(wptr + (2 * h) * wpass, sb + (2 * h) * (NT * 16u));
+    glds16_m0(wptr + (2 * h + 1) * wpass, sb + (2 * h + 1) * (NT * 16u));
+  };
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nkt = (p.Ktot + BK - 1) / BK;
+  f32x4 acc[NJ][MI];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 pa[8], wb[4];                                  // pixel subtile (4 fragments x 2 k-halves), one weight subtile (2 x 2): 48 VGPRs
+  // Fragment addresses: row = 16-aligned base + fr, so the chunk swizzle (row >> 1) & 7 depends on the lane only and every
+  // fragment of a stage is ONE of two per-lane byte addresses (k-half 0 / 1) plus a compile-time offset (ds_read offset field).
+  const int sw = (fr >> 1) & 7;
+  const char* ldsb = reinterpret_cast<const char*>(lds);
+  const char* pb[2] = {ldsb + (grp * 128 + fr) * 128 + ((fg ^ sw) * 16), ldsb + (grp * 128 + fr) * 128 + (((4 + fg) ^ sw) * 16)};
+  const char* wbp[2] = {ldsb + (BM + wq * 64 + fr) * 128 + ((fg ^ sw) * 16), ldsb + (BM + wq * 64 + fr) * 128 + (((4 + fg) ^ sw) * 16)};
+  auto read_p = [&](unsigned so, int ps) {             // so: byte offset of the stage (0 or 64 KB), one v_add per base per tile
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        pa[kh * 4 + i] = *reinterpret_cast<const uint4*>(pb[kh] + so + (ps * 64 + i * 16) * 128);
+  };
+  auto read_w = [&](unsigned so, int ws) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wb[kh * 2 + j] = *reinterpret_cast<const uint4*>(wbp[kh] + so + (ws * 32 + j * 16) * 128);
+  };
+  // `mid` runs after the first four MFMAs: with CLEARCAM_PHASE_FLAGS bit 2 the phase's DMA pieces are issued there, under the
+  // wave's own matrix work, instead of lengthening the read segment the other group's MFMAs are waiting behind
+  auto mma = [&](int ps, int ws, auto&& mid) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Mma<T>::run(wb[kh * 2 + j], pa[kh * 4 + i], acc[ws * 2 + j][ps * 4 + i]);
+        if (kh == 0 && j == 0) { __builtin_amdgcn_sched_barrier(0); mid(); __builtin_amdgcn_sched_barrier(0); }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto end_read = [&]() {                              // retire this wave's LDS reads, then meet the other group
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto end_mma = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: tile 0 complete, the pixels of tile 1 in flight ----------------------------------------------------------------
+  // DMA is issued unconditionally: past the last K tile the walk stops advancing, so the surplus pieces re-read the last tile
+  // into stage slots nobody reads any more (straight-line phases; the queue is drained before the epilogue re-uses the LDS).
+  int pt = 0, wt = 0;                                  // K tile the pixel / weight walk points at
+  auto step_w = [&]() { if (wt + 1 < nkt) { wptr += BK * sizeof(T); ++wt; } };
+  auto step_p = [&]() { if (pt + 1 < nkt) { advance_p(); ++pt; } };
+  constexpr unsigned SB = STAGE * 16u;                 // bytes per stage
+  issue_p(0, 0); issue_p(0, 1); step_p();
+  issue_w(0, 0); issue_w(0, 1); step_w();
+  issue_p(SB, 0);
+  wait_vmcnt<2>();
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0 from here on
+  __builtin_amdgcn_sched_barrier(0);
+
+  // one K tile per iteration; `so` = this tile's stage, `no` = the other one (tile t+1 is completed there, tile t+2 starts here)
+  const bool early_w = a.flags & 1, late_wait = (a.flags & 2) && grp == 0;
+  auto nothing = [] {};
+  if (a.flags & 24) {
+    // ABLATIONS (timing only, wrong results): bit 3 = MFMA segments only (operands of tile 0 stay in registers, no LDS reads, no
+    // DMA in the loop); bit 4 = LDS reads + MFMA, no DMA in the loop.  Barriers as in the real loop.
+    read_w(0, 0); read_p(0, 0);
+    for (int t = 0; t < nkt; ++t) {
+      const unsigned so = (t & 1) ? SB : 0u;
+      if (a.flags & 16) { read_w(so, 0); read_p(so, 0); }
+      end_read(); mma(0, 0, nothing); end_mma();
+      if (a.flags & 16) read_w(so, 1);
+      end_read(); mma(0, 1, nothing); end_mma();
+      if (a.flags & 16) read_p(so, 1);
+      end_read(); mma(1, 1, nothing); end_mma();
+      if (a.flags & 16) read_w(so, 0);
+      end_read(); mma(1, 0, nothing); end_mma();
+    }
+  } else if (a.flags & 4) {
+    // DMA issued inside the MFMA segments: P1(t+1) + W0(t+1) under phase 1, W1(t+1) under phase 2, P0(t+2) under phase 4; every
+    // piece outstanding at the phase-4 wait belongs to tile t+1, so that wait is vmcnt(0) and still leaves 2.5-4 phases per piece
+    for (int t = 0; t < nkt; ++t) {
+      const unsigned so = (t & 1) ? SB : 0u, no = SB - so;
+      read_w(so, 0); read_p(so, 0);
+      end_read(); mma(0, 0, [&] { issue_p(no, 1); step_p(); issue_w(no, 0); }); end_mma();
+      read_w(so, 1);
+      end_read(); mma(0, 1, [&] { issue_w(no, 1); step_w(); }); end_mma();
+      read_p(so, 1);
+      end_read(); mma(1, 1, nothing); end_mma();
+      read_w(so, 0);
+      wait_vmcnt<0>();                                                       // tile t+1 has landed
+      end_read(); mma(1, 0, [&] { issue_p(so, 0); }); end_mma();
+    }
+  } else
+  for (int t = 0; t < nkt; ++t) {
+    const unsigned so = (t & 1) ? SB : 0u, no = SB - so;
+    read_w(so, 0); read_p(so, 0);
+    issue_p(no, 1); step_p();                                                // pixels of tile t+1, rows 128..255
+    if (early_w) issue_w(no, 0);                                             // (the other stage's weights were last read in phase 4 of tile t-1)
+    end_read(); mma(0, 0, nothing); end_mma();
+    read_w(so, 1);
+    if (early_w) { issue_w(no, 1); step_w(); } else issue_w(no, 0);          // weights of tile t+1
+    end_read(); mma(0, 1, nothing); end_mma();
+    read_p(so, 1);
+    if (!early_w) { issue_w(no, 1); step_w(); }
+    end_read(); mma(1, 1, nothing); end_mma();
+    read_w(so, 0);                                                           // W subtile 0 again (one weight buffer in registers)
+    issue_p(so, 0);                                                          // pixels of tile t+2, rows 0..127 (this stage's were last read in phase 3)
+    // tile t+1 must have landed for EVERY wave before anybody reads it in the next phase 1.  Group 1 runs one barrier behind,
+    // so group 0 may do its wait after this phase's MFMAs (one more segment for its DMA to land), group 1 may not.
+    if (!late_wait) wait_vmcnt<2>();
+    end_read(); mma(1, 0, nothing);
+    if (late_wait) wait_vmcnt<2>();
+    end_mma();
+  }
+  wait_vmcnt<0>();
+  if (grp == 0) __builtin_amdgcn_s_barrier();          // group 0 waits for group 1's last segment
+  conv_epilogue<T, BM, BN, 2, MI, NJ, NT, true>(p, acc, n0, lds, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; });
+}
+
+template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * 512 * 8 * 16 + 512 * 4 * 16;     // two K tiles of (256 + 256) rows x 128 bytes + the per-row loader table
+  static bool configured = false;
+  if (!configured) {
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  static int flags = -1;
+  if (flags < 0) { const char* e = getenv("CLEARCAM_PHASE_FLAGS"); flags = e ? atoi(e) : 0; }
+  ConvAux b = a; b.flags = flags;
+  hipLaunchKernelGGL((conv_phase_kernel<T>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
+}
+
+void launch_conv_phase(int dt, const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {
+  if (dt == F16) launch_phase<f16_t>(p, a, M, stream);
+  else launch_phase<bf16_t>(p, a, M, stream);
+}
+
+}  // namespace cc

@@ -865,4 +865,45 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
   CC_API_END
 }
 
+// Diagnostic: average device time of ONE conv launch (random bf16/f16 data resident in HBM, weights packed once), hipEvents
+// on a private stream around `iters` back-to-back launches after 3 warm-up launches.  variant as ConvP::variant.
+int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int variant, int iters, float* ms) {
+  CC_API_BEGIN
+  CC_CHECK(ms && iters > 0 && (dtype == F16 || dtype == BF16), "bad argument");
+  HostTensor w, b;
+  w.shape = {Cout, Cin, k, k};
+  w.data.resize((size_t)Cout * Cin * k * k);
+  uint32_t st = 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
+  const float sc = 2.0f / sqrtf((float)Cin * k * k);
+  for (auto& v : w.data) v = rnd() * sc;
+  b.shape = {Cout}; b.data.assign(Cout, 0.01f);
+  PackedConv pc = pack_convs(dtype, {&w}, {&b}, {1}, 0);
+  const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * Ho * Wo * Cout;
+  std::vector<float> hx(std::min<size_t>(nin, (size_t)1 << 24));
+  for (auto& v : hx) v = rnd() * 2.0f;
+  std::vector<char> hx16(hx.size() * 2);
+  convert_f32_to(dtype, hx.data(), hx16.data(), hx.size());
+  char *x = nullptr, *out = nullptr;
+  CC_HIP(hipMalloc((void**)&x, nin * 2 + 256)); CC_HIP(hipMalloc((void**)&out, nout * 2 + 256));
+  for (size_t off = 0; off < nin * 2; off += hx16.size()) CC_HIP(hipMemcpy(x + off, hx16.data(), std::min(hx16.size(), nin * 2 - off), hipMemcpyHostToDevice));
+  ConvP c{};
+  c.s0 = Src{x, H, W, Cin, 0, Cin, 0}; c.s1 = Src{x, 1, 1, 0, 0, 0, 0};
+  c.B = B; c.Hin = H; c.Win = W; c.Cin = Cin; c.ks = k; c.stride = stride; c.pad = pad; c.Ho = Ho; c.Wo = Wo; c.Cout = Cout;
+  c.Ktot = k * k * Cin; c.Kw = pc.kw; c.w = pc.w; c.bias = pc.bias; c.out = out; c.out_cstride = Cout; c.act = act; c.variant = variant;
+  hipStream_t s; CC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t e0, e1; CC_HIP(hipEventCreate(&e0)); CC_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) launch_conv(dtype, c, s);
+  CC_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) launch_conv(dtype, c, s);
+  CC_HIP(hipEventRecord(e1, s));
+  CC_HIP(hipStreamSynchronize(s));
+  float t = 0; CC_HIP(hipEventElapsedTime(&t, e0, e1));
+  *ms = t / iters;
+  hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+  hipFree(x); hipFree(out); hipFree(pc.w); hipFree(pc.bias);
+  CC_API_END
+}
+
 }  // extern "C"

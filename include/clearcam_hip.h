@@ -72,6 +72,9 @@ void cc_yolo_destroy(cc_yolo* h);
 int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, const float* w_oihw,
                    const float* bias, int Cout, int k, int stride, int groups, int act, void* out_dev,
                    int force_direct, void* stream);
+/* Diagnostic (kernel tuning, tools/dev/phase_ab.py): average device milliseconds of one launch of the conv above on random
+ * 16-bit data resident in HBM, weights packed once, `iters` launches between two events.  Not part of the drop-in surface. */
+int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int variant, int iters, float* ms);
 
 /* ---------------------------------------------------------------------------------------------
  * CLIP — stands behind `OpenCLIP.precompute_embedding(x)` (models/objects.py:94-133) and

@@ -76,3 +76,21 @@ def test_face_path_against_committed_golden():
     cubic = preprocess_crops([g["crop"]]).cpu().numpy()[0]
     ref = np.transpose((g["crop_cubic_224"].astype(np.float32) / 255.0 - 0.5) / 0.5, (2, 0, 1))
     assert np.array_equal(cubic, ref.astype(np.float32))
+
+
+def test_kernels_reproduce_the_hand_computed_opencv_cases():
+    """The GPU kernels against tests/cv_kats.py: expected bytes derived by hand from OpenCV's fixed-point constants
+    (11-bit cubic / linear coefficients, (sum + 2^21) >> 22, replicate border, the 2x-decimation area rule, warpAffine's
+    5-bit sub-pixel grid and 15-bit weights) - independent of oracle/cv_*_oracle.py."""
+    import cv_kats as K
+    from clearcam_amd import cvops
+    from clearcam_amd.objects import preprocess_crops
+    for case in (K.cubic_2x_impulse, K.cubic_2x_corner):
+        src, size, exp = case()
+        got = preprocess_crops([src], size[0]).cpu().numpy()[0]                     # (3,8,8) float32 = (v/255 - 0.5)/0.5
+        want = ((exp.astype(np.float32) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5)).transpose(2, 0, 1)
+        assert np.array_equal(got, want), case.__name__
+    for src, dsize, exp in K.linear_cases():
+        assert np.array_equal(cvops.resize_linear(src, dsize), exp), dsize
+    for src, M, dsize, exp in K.warp_cases():
+        assert np.array_equal(cvops.warp_affine(src, M, dsize), exp), M.tolist()

@@ -377,7 +377,7 @@ BIG_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [5, 6], ids=["tile256", "tile128"])
+@pytest.mark.parametrize("variant", [5, 6, 7], ids=["tile256", "tile128", "pingpong256"])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("case", BIG_CASES, ids=[c[0] for c in BIG_CASES])
 def test_big_tile_kernel_matches_torch(case, dtype, variant):
@@ -388,7 +388,7 @@ def test_big_tile_kernel_matches_torch(case, dtype, variant):
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
     b = torch.randn(Cout, generator=g) * 0.1
     ref = F.silu(F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b, padding=k // 2))
-    got = conv_hip(x, w, b, 1, 1, 1, dtype, force_direct=variant)        # 5: 256x256 tiles, 6: 128x128 tiles, same schedule
+    got = conv_hip(x, w, b, 1, 1, 1, dtype, force_direct=variant)        # 5: 256x256 tiles, 6: 128x128 tiles, same schedule; 7: eight-wave two-group kernel
     assert float((got - ref).abs().max() / ref.abs().max()) <= TOL[dtype]
 
 
