@@ -81,9 +81,17 @@ def split_words(text: str, specials=("<start_of_text>", "<end_of_text>")) -> Lis
 
 
 class SimpleTokenizer:
-    def __init__(self, bpe_path: Optional[str] = None, context_length: int = CONTEXT):
-        lines = gzip.open(find_vocab(bpe_path)).read().decode("utf-8").split("\n")
-        merges: List[Tuple[str, str]] = [tuple(l.split()) for l in lines[1:_N_MERGES + 1]]
+    def __init__(self, bpe_path: Optional[str] = None, context_length: int = CONTEXT, sparse_merges: Optional[Dict[Tuple[str, str], int]] = None):
+        """bpe_path / $CLEARCAM_BPE_VOCAB / the usual locations name clearcam's ``bpe_simple_vocab_16e6.txt.gz``.
+        sparse_merges (tests): {(left, right): rank} for a SUBSET of the published merge table, ranks as published — enough to
+        tokenise the strings it was cut for exactly (every merge those strings can ever look up must be present)."""
+        if sparse_merges is not None:
+            merges: List[Tuple[str, str]] = [("\x00unused", str(i)) for i in range(_N_MERGES)]      # placeholders keep the id layout
+            for pair, rank in sparse_merges.items():
+                merges[rank] = tuple(pair)
+        else:
+            lines = gzip.open(find_vocab(bpe_path)).read().decode("utf-8").split("\n")
+            merges = [tuple(l.split()) for l in lines[1:_N_MERGES + 1]]
         self.byte_map = _byte_alphabet()
         alphabet = list(self.byte_map.values())
         # id order of the published vocab: bytes in keep-then-extra order, the same with </w>, merges, specials

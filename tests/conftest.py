@@ -56,3 +56,12 @@ def sd_c():
 def noise_frames(seed, b, h, w, dtype=np.uint8):
     f = np.random.default_rng(seed).integers(0, 256, (b, h, w, 3), dtype=np.uint8)
     return f if dtype == np.uint8 else f.astype(dtype)
+
+
+def sparse_tokenizer():
+    """SimpleTokenizer over tests/golden/bpe_merges_subset.json: the merges (published ranks) that the strings of
+    tokenizer_kats.json can look up, so the string surface is testable where clearcam's vocabulary file is absent."""
+    import json
+    from clearcam_amd.clip_tokenizer import SimpleTokenizer
+    sub = json.load(open(os.path.join(ROOT, "tests", "golden", "bpe_merges_subset.json")))["merges"]
+    return SimpleTokenizer(sparse_merges={tuple(k.split(" ")): r for k, r in sub.items()})

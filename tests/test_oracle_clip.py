@@ -57,6 +57,18 @@ def test_tokenizer_matches_reference_ids():
     assert m.shape == (1, 77) and m[0, :6].tolist() == [49406, 9606, 325, 275, 271, 49407] and m[0, 6:].sum() == 0
 
 
+def test_tokenizer_on_the_committed_merge_subset():
+    """The same KATs (ids produced by the reference's own tokenizer) without clearcam's vocabulary file: the committed subset
+    of its merge table carries every merge those strings can look up (tools/make_vocab_subset.py)."""
+    from conftest import sparse_tokenizer
+    k = json.load(open(os.path.join(GOLD, "tokenizer_kats.json")))
+    t = sparse_tokenizer()
+    assert (t.vocab_size, t.sot_token_id, t.eot_token_id) == (49408, 49406, 49407)
+    for c in k["cases"]:
+        assert t.encode(c["text"]) == c["ids"], c["text"]
+    assert t.tokens_for_model("  Ferrari   F40 ")[0, :6].tolist() == [49406, 9606, 325, 275, 271, 49407]
+
+
 def test_split_words_pattern():
     from clearcam_amd.clip_tokenizer import split_words
     assert split_words("it's 42nd st.!!") == ["it", "'s", "4", "2", "nd", "st", ".!!"]
