@@ -815,13 +815,12 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
       const bool fits = p.Ktot >= 1024 && tiles >= 256 && rounds * 256 * 100 <= tiles * 112;
       // layers with a residual keep the 128x128 kernel: their f32 read-modify-write epilogue needs another block to hide behind
       if ((big > 0 && fits && !p.res && p.variant == 0) || big < 0 || p.variant == 5 || p.variant == 7) bn = 256;
-      // The eight-wave two-group kernel (conv_phase.hip).  Per-layer A/B on YOLOv9-C B=64 and on the CLIP GEMMs (profiles/r02b):
-      // 5-18 % faster than the kernels above for 1x1 / stride-2 layers with >= 400 tiles of 256x256 and for every CLIP GEMM
-      // (with or without the f32 residual epilogue), equal on the 3x3 stride-1 layers (kept on their kernels), slower below
-      // ~400 tiles (one block per CU: a 100-tile layer leaves 156 CUs idle).  CLEARCAM_PHASE=0 disables, 1 forces it for
-      // every eligible layer.
+      // The eight-wave two-group kernel (conv_phase.hip).  Per-layer A/B on YOLOv9-C B=64 and on the CLIP GEMMs (profiles/r02c):
+      // 5-18 % faster than the kernels above for layers with >= 400 tiles of 256x256 and for every CLIP GEMM (with or without
+      // the f32 residual epilogue), slower below ~400 tiles (one block per CU: a 100-tile layer leaves 156 CUs idle).
+      // CLEARCAM_PHASE=0 disables, 1 forces it for every eligible layer.
       const bool simple1 = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
-      const bool phase_rule = tiles >= 400 && (p.ks == 1 || p.stride == 2);
+      const bool phase_rule = tiles >= 400;
       if (p.variant == 0 && simple1 && p.Cin % 64 == 0 && (phase == 1 || (phase != 0 && phase_rule))) { bn = 256; use_phase = true; }
     }
   }

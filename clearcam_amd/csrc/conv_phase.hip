@@ -22,7 +22,7 @@ namespace cc {
 // pixel pieces (HBM / far L2) have four to five phases to land, weight pieces (L2 hits) one to two, and the queue is never
 // drained in the main loop.  Every wave's ds_reads are retired
 // (lgkmcnt(0)) BEFORE the barrier that ends its read segment, which is what allows a slot to be re-used one phase later.
-template <class T>
+template <class T, int SCHED>
 __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const ConvAux a) {
   constexpr int BM = 256, BN = 256, NT = 512, MI = 8, NJ = 4;
   constexpr int E = 8, CPRW = 8, BK = 64, RPP = NT / CPRW, XR = BM / RPP, WR = BN / RPP;   // 64 rows per pass, 4 passes per operand
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   uint4 pa[8], wb[4];                                  // pixel subtile (4 fragments x 2 k-halves), one weight subtile (2 x 2): 48 VGPRs
+  uint4 wb1[4];                                        // SCHED 1 keeps both weight subtiles in registers
   // Fragment addresses: row = 16-aligned base + fr, so the chunk swizzle (row >> 1) & 7 depends on the lane only and every
   // fragment of a stage is ONE of two per-lane byte addresses (k-half 0 / 1) plus a compile-time offset (ds_read offset field).
   const int sw = (fr >> 1) & 7;
@@ -145,17 +146,25 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   };
   // `mid` runs after the first four MFMAs: with CLEARCAM_PHASE_FLAGS bit 2 the phase's DMA pieces are issued there, under the
   // wave's own matrix work, instead of lengthening the read segment the other group's MFMAs are waiting behind
-  auto mma = [&](int ps, int ws, auto&& mid) {
+  auto mma_w = [&](int ps, int ws, const uint4 (&wv)[4], auto&& mid) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Mma<T>::run(wb[kh * 2 + j], pa[kh * 4 + i], acc[ws * 2 + j][ps * 4 + i]);
+        for (int i = 0; i < 4; ++i) Mma<T>::run(wv[kh * 2 + j], pa[kh * 4 + i], acc[ws * 2 + j][ps * 4 + i]);
         if (kh == 0 && j == 0) { __builtin_amdgcn_sched_barrier(0); mid(); __builtin_amdgcn_sched_barrier(0); }
       }
     __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma = [&](int ps, int ws, auto&& mid) { mma_w(ps, ws, wb, mid); };
+  auto read_w1 = [&](unsigned so) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wb1[kh * 2 + j] = *reinterpret_cast<const uint4*>(wbp[kh] + so + (32 + j * 16) * 128);
   };
   auto end_read = [&]() {                              // retire this wave's LDS reads, then meet the other group
     __builtin_amdgcn_sched_barrier(0);
@@ -170,13 +179,45 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: tile 0 complete, the pixels of tile 1 in flight ----------------------------------------------------------------
-  // DMA is issued unconditionally: past the last K tile the walk stops advancing, so the surplus pieces re-read the last tile
-  // into stage slots nobody reads any more (straight-line phases; the queue is drained before the epilogue re-uses the LDS).
   int pt = 0, wt = 0;                                  // K tile the pixel / weight walk points at
   auto step_w = [&]() { if (wt + 1 < nkt) { wptr += BK * sizeof(T); ++wt; } };
   auto step_p = [&]() { if (pt + 1 < nkt) { advance_p(); ++pt; } };
   constexpr unsigned SB = STAGE * 16u;                 // bytes per stage
+  auto nothing = [] {};
+  // DMA is issued unconditionally: past the last K tile the walks stop advancing, so the surplus pieces re-read the last tile
+  // into stage slots nobody reads any more (straight-line phases; the queue is drained before the epilogue re-uses the LDS).
+  if constexpr (SCHED == 1) {
+    // ---- schedule 1: LDS reads are NOT retired before the barrier (they complete while the wave waits there and under the first
+    // MFMAs: the compiler's own lgkmcnt ladder), so a slot is re-used two phases after its last read at the earliest.  Both
+    // weight subtiles stay in registers (no re-read in phase 4), which frees a stage's weight slots after phase 2:
+    //     phase of tile t:   1          2          3        4
+    //     read (stage so):   W0, P0     W1         P1       -
+    //     issue:             P0(t+1)    P1(t+1)    -        W0(t+2), W1(t+2) -> so ; vmcnt(4): tile t+1 complete
+    // weights travel five phases ahead of their use, pixels three to four.
+    auto sync = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
+    issue_p(0, 0); issue_p(0, 1); step_p();
+    issue_w(0, 0); issue_w(0, 1); step_w();
+    issue_w(SB, 0); issue_w(SB, 1); step_w();
+    wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0 from here on
+    __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < nkt; ++t) {
+      const unsigned so = (t & 1) ? SB : 0u, no = SB - so;
+      read_w(so, 0); read_p(so, 0);
+      issue_p(no, 0);
+      sync(); mma_w(0, 0, wb, nothing); sync();
+      read_w1(so);
+      issue_p(no, 1); step_p();
+      sync(); mma_w(0, 1, wb1, nothing); sync();
+      read_p(so, 1);
+      sync(); mma_w(1, 1, wb1, nothing); sync();
+      issue_w(so, 0); issue_w(so, 1); step_w();
+      wait_vmcnt<4>();                                                       // tile t+1 has landed
+      sync(); mma_w(1, 0, wb, nothing); sync();
+    }
+  } else {
+  // ---- schedule 0: reads retired before the barrier, one weight buffer (W subtile 0 is read again in phase 4) ------------------
   issue_p(0, 0); issue_p(0, 1); step_p();
   issue_w(0, 0); issue_w(0, 1); step_w();
   issue_p(SB, 0);
@@ -184,10 +225,6 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0 from here on
   __builtin_amdgcn_sched_barrier(0);
-
-  // one K tile per iteration; `so` = this tile's stage, `no` = the other one (tile t+1 is completed there, tile t+2 starts here)
-  const bool early_w = a.flags & 1, late_wait = (a.flags & 2) && grp == 0;
-  auto nothing = [] {};
   if (a.flags & 24) {
     // ABLATIONS (timing only, wrong results): bit 3 = MFMA segments only (operands of tile 0 stay in registers, no LDS reads, no
     // DMA in the loop); bit 4 = LDS reads + MFMA, no DMA in the loop.  Barriers as in the real loop.
@@ -203,42 +240,23 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
       if (a.flags & 16) read_w(so, 0);
       end_read(); mma(1, 0, nothing); end_mma();
     }
-  } else if (a.flags & 4) {
-    // DMA issued inside the MFMA segments: P1(t+1) + W0(t+1) under phase 1, W1(t+1) under phase 2, P0(t+2) under phase 4; every
-    // piece outstanding at the phase-4 wait belongs to tile t+1, so that wait is vmcnt(0) and still leaves 2.5-4 phases per piece
-    for (int t = 0; t < nkt; ++t) {
-      const unsigned so = (t & 1) ? SB : 0u, no = SB - so;
-      read_w(so, 0); read_p(so, 0);
-      end_read(); mma(0, 0, [&] { issue_p(no, 1); step_p(); issue_w(no, 0); }); end_mma();
-      read_w(so, 1);
-      end_read(); mma(0, 1, [&] { issue_w(no, 1); step_w(); }); end_mma();
-      read_p(so, 1);
-      end_read(); mma(1, 1, nothing); end_mma();
-      read_w(so, 0);
-      wait_vmcnt<0>();                                                       // tile t+1 has landed
-      end_read(); mma(1, 0, [&] { issue_p(so, 0); }); end_mma();
-    }
   } else
   for (int t = 0; t < nkt; ++t) {
     const unsigned so = (t & 1) ? SB : 0u, no = SB - so;
     read_w(so, 0); read_p(so, 0);
     issue_p(no, 1); step_p();                                                // pixels of tile t+1, rows 128..255
-    if (early_w) issue_w(no, 0);                                             // (the other stage's weights were last read in phase 4 of tile t-1)
     end_read(); mma(0, 0, nothing); end_mma();
     read_w(so, 1);
-    if (early_w) { issue_w(no, 1); step_w(); } else issue_w(no, 0);          // weights of tile t+1
+    issue_w(no, 0);                                                          // weights of tile t+1, rows 0..127
     end_read(); mma(0, 1, nothing); end_mma();
     read_p(so, 1);
-    if (!early_w) { issue_w(no, 1); step_w(); }
+    issue_w(no, 1); step_w();                                                // weights of tile t+1, rows 128..255
     end_read(); mma(1, 1, nothing); end_mma();
     read_w(so, 0);                                                           // W subtile 0 again (one weight buffer in registers)
     issue_p(so, 0);                                                          // pixels of tile t+2, rows 0..127 (this stage's were last read in phase 3)
-    // tile t+1 must have landed for EVERY wave before anybody reads it in the next phase 1.  Group 1 runs one barrier behind,
-    // so group 0 may do its wait after this phase's MFMAs (one more segment for its DMA to land), group 1 may not.
-    if (!late_wait) wait_vmcnt<2>();
-    end_read(); mma(1, 0, nothing);
-    if (late_wait) wait_vmcnt<2>();
-    end_mma();
+    wait_vmcnt<2>();                                                         // tile t+1 has landed
+    end_read(); mma(1, 0, nothing); end_mma();
+  }
   }
   wait_vmcnt<0>();
   if (grp == 0) __builtin_amdgcn_s_barrier();          // group 0 waits for group 1's last segment
@@ -249,13 +267,15 @@ template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, in
   constexpr size_t lds = (size_t)2 * 512 * 8 * 16 + 512 * 4 * 16;     // two K tiles of (256 + 256) rows x 128 bytes + the per-row loader table
   static bool configured = false;
   if (!configured) {
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
   static int flags = -1;
-  if (flags < 0) { const char* e = getenv("CLEARCAM_PHASE_FLAGS"); flags = e ? atoi(e) : 0; }
+  if (flags < 0) { const char* e = getenv("CLEARCAM_PHASE_FLAGS"); flags = e ? atoi(e) : 32; }   // 32: schedule 1 (default); 0: schedule 0; 8 / 16: timing ablations of schedule 0
   ConvAux b = a; b.flags = flags;
-  hipLaunchKernelGGL((conv_phase_kernel<T>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
+  if (flags & 32) hipLaunchKernelGGL((conv_phase_kernel<T, 1>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
+  else hipLaunchKernelGGL((conv_phase_kernel<T, 0>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
 }
 
 void launch_conv_phase(int dt, const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {

@@ -23,6 +23,7 @@ struct cc_index {
   size_t row_bytes() const { return (size_t)dim * (storage == F32 ? 4 : 2); }
   hipStream_t stream = nullptr;
   float* q_dev = nullptr; int q_cap = 0;
+  uint16_t* q16 = nullptr; int q16_cap = 0;     // bf16 copy of the queries (bf16 index, many queries: one MFMA GEMM pass)
   float* scores = nullptr; size_t scores_cap = 0;
   unsigned long long* cand = nullptr; size_t cand_cap = 0;
   int* idx_dev = nullptr; float* sc_dev = nullptr; size_t out_cap = 0;
@@ -318,6 +319,14 @@ void compute_scores(cc_index* h, int Q, hipStream_t s) {
   // Sixteen GEMV passes for 64 queries become one.  Products are exact f32 either way; only the summation order differs
   // from the GEMV kernel (last-bit differences between the two paths).
   static const bool wide = [] { const char* e = getenv("CLEARCAM_SCAN"); return e ? atoi(e) != 0 : true; }();
+  if (h->storage == BF16 && Q > 16 && h->n % 8 == 0 && h->n < (1L << 31)) {
+    // many queries against bf16 rows: ONE pass as a bf16 MFMA GEMM (queries rounded to bf16 as well: scores within ~2e-3 of f32)
+    if (h->q16_cap < Q) { if (h->q16) hipFree(h->q16); CC_HIP(hipMalloc((void**)&h->q16, (size_t)Q * h->dim * 2 + 256)); h->q16_cap = Q; }
+    const size_t cnt = (size_t)Q * h->dim;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->q_dev, h->q16, cnt);
+    const ConvP g = gemm_params(h->q16, h->dim, Q, h->dim, h->emb, h->dim, nullptr, (int)h->n, h->scores, (int)h->n, 1, 0, nullptr, 0, 0);
+    if (conv_mfma_supported(BF16, g)) { launch_conv_mfma(BF16, g, s); return; }
+  }
   if (h->storage == BF16) {                         // bf16 rows: 8 queries per pass over half the bytes (dim % 256 == 0 is checked at create)
     for (int q0 = 0; q0 < Q; q0 += 8) {
       const float* q = h->q_dev + (size_t)q0 * h->dim; float* out = h->scores + (size_t)q0 * h->n;
@@ -525,7 +534,7 @@ void cc_index_destroy(cc_index* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  for (void* p : {(void*)h->emb, (void*)h->grp, (void*)h->allowed, (void*)h->q_dev, (void*)h->scores, (void*)h->cand, (void*)h->idx_dev, (void*)h->sc_dev}) if (p) hipFree(p);
+  for (void* p : {(void*)h->emb, (void*)h->grp, (void*)h->allowed, (void*)h->q16, (void*)h->q_dev, (void*)h->scores, (void*)h->cand, (void*)h->idx_dev, (void*)h->sc_dev}) if (p) hipFree(p);
   if (h->pin) hipHostFree(h->pin);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
