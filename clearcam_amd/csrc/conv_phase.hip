@@ -3,6 +3,22 @@
 
 namespace cc {
 
+typedef int srd_t __attribute__((ext_vector_type(4)));
+// LDS-DMA through a buffer descriptor: 32-bit per-lane byte offset, rows past `bytes` (and the 0xffffffff "no such row"
+// offset of halo taps) read as zero in hardware - no zero page, no 64-bit address VGPRs.
+__device__ __forceinline__ srd_t make_srd(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  srd_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void bdma16(unsigned voff, srd_t srd, unsigned lds_wave_byte_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(srd), "s"(lds_wave_byte_addr) : "memory", "m0");
+}
+
 // ---- 256 x 256 tile, EIGHT waves in two groups that alternate an LDS/DMA segment and an MFMA segment -----------------------
 // The four-wave kernel above leaves one wave per SIMD: whenever that wave reads LDS, issues DMA or waits at its barrier the
 // SIMD's matrix pipe idles.  Here two waves share each SIMD (waves w and w+4) and run half a phase apart, so that while one
@@ -48,9 +64,12 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   // Per pixel row: the byte address of (its window's top-left pixel, channel coff) and the 9-bit tap-validity mask.  They are
   // only needed when the K walk crosses into the next filter tap (every Cin/64 tiles), so they live in the 24 KB of LDS behind
   // the two K-tile stages instead of in 12 VGPRs that the accumulators need.
+  constexpr bool BUF = SCHED == 2;                     // DMA through buffer descriptors (32-bit offsets, hardware zero fill)
   struct RowInfo { const char* ptr; unsigned mask; unsigned pad; };
   RowInfo* rinfo = reinterpret_cast<RowInfo*>(lds + 2 * STAGE) + tid * XR;
   const char* cur[XR]; unsigned inc[XR];
+  unsigned cur32[XR];                                  // BUF: byte offsets from p.s0.ptr
+  const srd_t srd_x = make_srd(p.s0.ptr, (unsigned)a.x_bytes), srd_w = make_srd(p.w, (unsigned)a.w_bytes);
 #pragma unroll
   for (int i = 0; i < XR; ++i) {
     const int m = m0 + prow + RPP * i;
@@ -89,7 +108,8 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
     for (int i = 0; i < XR; ++i) {
       const RowInfo ri = rinfo[i];
       const bool ok = (ri.mask >> tap) & 1u;
-      cur[i] = ok ? ri.ptr + delta : reinterpret_cast<const char*>(&g_zero16);
+      if constexpr (BUF) cur32[i] = ok ? (unsigned)((ri.ptr + delta) - reinterpret_cast<const char*>(p.s0.ptr)) : 0xffffffffu;
+      else cur[i] = ok ? ri.ptr + delta : reinterpret_cast<const char*>(&g_zero16);
       inc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
     }
   };
@@ -99,20 +119,22 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
     if (kc == p.Cin) { kc = 0; ++tap; retarget(); }
     else {
 #pragma unroll
-      for (int i = 0; i < XR; ++i) cur[i] += inc[i];
+      for (int i = 0; i < XR; ++i) { if constexpr (BUF) cur32[i] += inc[i]; else cur[i] += inc[i]; }
     }
   };
   const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * 64) * 16u);
   // half-tile h of the pixels / weights of a K tile -> passes 2h, 2h+1 of that operand's slab in `stage`
   auto issue_p = [&](unsigned stage_bytes, int h) {
     const unsigned sb = wave_lds + stage_bytes;
-    glds16_m0(cur[2 * h], sb + (2 * h) * (NT * 16u));
-    glds16_m0(cur[2 * h + 1], sb + (2 * h + 1) * (NT * 16u));
+    if constexpr (BUF) { bdma16(cur32[2 * h], srd_x, sb + (2 * h) * (NT * 16u)); bdma16(cur32[2 * h + 1], srd_x, sb + (2 * h + 1) * (NT * 16u)); }
+    else { glds16_m0(cur[2 * h], sb + (2 * h) * (NT * 16u)); glds16_m0(cur[2 * h + 1], sb + (2 * h + 1) * (NT * 16u)); }
   };
   auto issue_w = [&](unsigned stage_bytes, int h) {
     const unsigned sb = wave_lds + stage_bytes + (unsigned)(BM * CPRW) * 16u;
-    glds16_m0(wptr + (2 * h) * wpass, sb + (2 * h) * (NT * 16u));
-    glds16_m0(wptr + (2 * h + 1) * wpass, sb + (2 * h + 1) * (NT * 16u));
+    if constexpr (BUF) {
+      const unsigned w32 = (unsigned)(wptr - reinterpret_cast<const char*>(p.w));
+      bdma16(w32 + (2 * h) * (unsigned)wpass, srd_w, sb + (2 * h) * (NT * 16u)); bdma16(w32 + (2 * h + 1) * (unsigned)wpass, srd_w, sb + (2 * h + 1) * (NT * 16u));
+    } else { glds16_m0(wptr + (2 * h) * wpass, sb + (2 * h) * (NT * 16u)); glds16_m0(wptr + (2 * h + 1) * wpass, sb + (2 * h + 1) * (NT * 16u)); }
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -186,7 +208,7 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   auto nothing = [] {};
   // DMA is issued unconditionally: past the last K tile the walks stop advancing, so the surplus pieces re-read the last tile
   // into stage slots nobody reads any more (straight-line phases; the queue is drained before the epilogue re-uses the LDS).
-  if constexpr (SCHED == 1) {
+  if constexpr (SCHED >= 1) {
     // ---- schedule 1: LDS reads are NOT retired before the barrier (they complete while the wave waits there and under the first
     // MFMAs: the compiler's own lgkmcnt ladder), so a slot is re-used two phases after its last read at the earliest.  Both
     // weight subtiles stay in registers (no re-read in phase 4), which frees a stage's weight slots after phase 2:
@@ -269,11 +291,16 @@ template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, in
   if (!configured) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
   static int flags = -1;
   if (flags < 0) { const char* e = getenv("CLEARCAM_PHASE_FLAGS"); flags = e ? atoi(e) : 32; }   // 32: schedule 1 (default); 0: schedule 0; 8 / 16: timing ablations of schedule 0
   ConvAux b = a; b.flags = flags;
+  const size_t xb = (size_t)p.B * p.s0.H * p.s0.W * p.s0.cstride * sizeof(T), wbytes = (size_t)p.Cout * p.Kw * sizeof(T);
+  const bool buf_ok = xb < ((size_t)1 << 32) - 256 && wbytes < ((size_t)1 << 32) - 256;
+  b.x_bytes = (unsigned)xb; b.w_bytes = (unsigned)wbytes;
+  if ((flags & 64) && buf_ok) { hipLaunchKernelGGL((conv_phase_kernel<T, 2>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b); return; }
   if (flags & 32) hipLaunchKernelGGL((conv_phase_kernel<T, 1>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
   else hipLaunchKernelGGL((conv_phase_kernel<T, 0>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
 }
