@@ -677,6 +677,8 @@ template <class T, int TS> static void launch_big(const ConvP& p, const ConvAux&
 }
 
 void launch_conv_phase(int dt, const ConvP& p, const ConvAux& a, int M, hipStream_t stream);   // conv_phase.hip
+bool conv_wave_legal(const ConvP& p);                                                            // conv_wave.hip
+void launch_conv_wave(int dt, const ConvP& p, hipStream_t stream);
 
 template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const ConvAux& a, int bn, int M, hipStream_t stream) {
   if (g_cfg[0] < 0) {
@@ -784,6 +786,19 @@ template <class T> static void launch_ws_t(const ConvP& p, hipStream_t stream) {
 template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   const int M = p.B * p.Ho * p.Wo;
   if constexpr (sizeof(T) == 2) {
+    {   // narrow 3x3 layers: one autonomous wave per 2x16-pixel sub-tile over LDS-resident weights (conv_wave.hip).
+        // CLEARCAM_WAVE=0 falls back to the cooperative kernels below; tests force it with variant 8.
+      static int wave_on = -1;
+      if (wave_on < 0) { const char* e = getenv("CLEARCAM_WAVE"); wave_on = e ? atoi(e) : 1; }
+      // measured (B=64): 64 -> 64 at 80x80 51 us vs 57 (weights-stationary) / 59 (generic), at 160x160 204 vs 223 / 262; 32 -> 32
+      // ties the weights-stationary kernel (61 vs 58 us) and a handful of sub-tiles (batch 1) is better served by the tile kernels
+      const long subtiles = (long)p.B * ((p.Ho + 1) / 2) * ((p.Wo + 15) / 16);
+      if (p.variant == 8 || (p.variant == 0 && wave_on && conv_wave_legal(p) && p.Cin == 64 && subtiles >= 4096)) {
+        CC_CHECK(conv_wave_legal(p), "wave-autonomous 3x3: shape not eligible");
+        launch_conv_wave(TypeTag<T>::dt, p, stream);
+        return;
+      }
+    }
     if (p.variant == 4 || (p.variant == 0 && ws_applicable(p))) {
       CC_CHECK(ws_legal(p), "weights-stationary 3x3: shape not eligible");
       launch_ws_t<T>(p, stream);

@@ -75,6 +75,13 @@ SPECIAL_CASES = [
     ("ws_64_32", 2, 64, 9, 17, 32, 4),
     ("ws_64_48", 1, 64, 16, 16, 48, 4),                  # Cout not a tile multiple
     ("generic_forced", 1, 64, 16, 16, 64, 2),
+    ("wave_64_64", 5, 64, 24, 48, 64, 8),                # more sub-tiles than waves: the persistent loop, patch prefetch under the epilogue
+    ("wave_64_64_ragged", 2, 64, 13, 21, 64, 8),         # odd height (half-used 2-row sub-tiles), ragged width
+    ("wave_32_32", 3, 32, 16, 32, 32, 8),                # sixteen waves per block, 64-byte rows
+    ("wave_32_64", 1, 32, 20, 30, 64, 8),
+    ("wave_64_32", 2, 64, 9, 17, 32, 8),
+    ("wave_1row", 1, 64, 1, 160, 64, 8),
+    ("wave_many", 64, 32, 40, 40, 32, 8),                # 51 200 sub-tiles: every wave walks several
 ]
 TOL = {"f32": 2e-5, "f16": 3e-3, "bf16": 2e-2}            # max |err| / max |ref|
 
