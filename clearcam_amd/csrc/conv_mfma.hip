@@ -815,7 +815,7 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   }
   auto padded = [&](int bn) { return (p.Cout + bn - 1) / bn * bn; };
   int bn = 128;
-  bool use_phase = false;
+  bool use_phase = false, use_two = false;
   if (padded(64) < padded(bn)) bn = 64;
   if (padded(32) < padded(bn)) bn = 32;
   {   // 256x256 tiles / four-wave single-barrier schedule (conv_big_kernel) for wide, deep, GEMM-shaped layers.
@@ -836,7 +836,10 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
       // CLEARCAM_PHASE=0 disables, 1 forces it for every eligible layer.
       const bool simple1 = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
       const bool phase_rule = tiles >= 400;
-      if (p.variant == 0 && simple1 && p.Cin % 64 == 0 && (phase == 1 || (phase != 0 && phase_rule))) { bn = 256; use_phase = true; }
+      // ... and the 1x1 convs that read a Concat (two sources, one possibly upsampled: the first conv of the neck's ELAN blocks)
+      const bool concat1 = p.s1.C > 0 && p.ks == 1 && p.stride == 1 && p.pad == 0 && p.s0.C % 64 == 0 && p.s1.C % 64 == 0;
+      use_two = concat1;
+      if ((p.variant == 0 || (p.variant == 7 && concat1)) && (simple1 || concat1) && p.Cin % 64 == 0 && (phase == 1 || p.variant == 7 || (phase != 0 && phase_rule))) { bn = 256; use_phase = true; }
     }
   }
   if (p.variant == 6) bn = 128;
@@ -846,6 +849,7 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
 
   const bool simple = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
   a.is1x1 = simple && p.ks == 1 && p.stride == 1 && p.pad == 0 && p.Hin == p.Ho && p.Win == p.Wo;
+  a.two = use_phase && use_two;
   if (use_phase) { if constexpr (sizeof(T) == 2) launch_conv_phase(TypeTag<T>::dt, p, a, M, stream); }
   else if (simple) launch_ts<T, true>(p, a, bn, M, stream); else launch_ts<T, false>(p, a, bn, M, stream);
   CC_HIP(hipGetLastError());

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   // only needed when the K walk crosses into the next filter tap (every Cin/64 tiles), so they live in the 24 KB of LDS behind
   // the two K-tile stages instead of in 12 VGPRs that the accumulators need.
   constexpr bool BUF = SCHED == 2;                     // DMA through buffer descriptors (32-bit offsets, hardware zero fill)
-  struct RowInfo { const char* ptr; unsigned mask; unsigned pad; };
+  struct RowInfo { const char* ptr; unsigned long long aux; };   // aux: tap-validity mask, or (two sources) the row's address in source 1
   RowInfo* rinfo = reinterpret_cast<RowInfo*>(lds + 2 * STAGE) + tid * XR;
   const char* cur[XR]; unsigned inc[XR];
   unsigned cur32[XR];                                  // BUF: byte offsets from p.s0.ptr
@@ -74,9 +74,16 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   for (int i = 0; i < XR; ++i) {
     const int m = m0 + prow + RPP * i;
     RowInfo ri;
-    if (a.is1x1) {
+    if (a.two) {                                       // Concat folded into the loader (detection/yolov9.py:151-155; Upsample :285-292 as index >> shift)
+      const int mm = m < M ? m : 0;
+      const int b = fdiv(mm, hw, a.inv_hw), rem = mm - b * hw, ho = fdiv(rem, p.Wo, a.inv_wo), wo = rem - ho * p.Wo;
+      const long i0 = ((long)b * p.s0.H + (ho >> p.s0.shift)) * p.s0.W + (wo >> p.s0.shift);
+      const long i1 = ((long)b * p.s1.H + (ho >> p.s1.shift)) * p.s1.W + (wo >> p.s1.shift);
+      ri.ptr = m < M ? reinterpret_cast<const char*>(p.s0.ptr) + (i0 * p.s0.cstride + p.s0.coff) * (long)sizeof(T) : nullptr;
+      ri.aux = (unsigned long long)(reinterpret_cast<const char*>(p.s1.ptr) + (i1 * p.s1.cstride + p.s1.coff) * (long)sizeof(T));
+    } else if (a.is1x1) {
       ri.ptr = reinterpret_cast<const char*>(p.s0.ptr) + ((size_t)m * p.s0.cstride + p.s0.coff) * sizeof(T);
-      ri.mask = m < M ? 1u : 0u;
+      ri.aux = m < M ? 1u : 0u;
     } else {
       const int mm = m < M ? m : 0;
       const int b = fdiv(mm, hw, a.inv_hw), rem = mm - b * hw, ho = fdiv(rem, p.Wo, a.inv_wo), wo = rem - ho * p.Wo;
@@ -88,11 +95,10 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
         wmk |= (unsigned)(r < p.ks && (unsigned)(w0 + r) < (unsigned)p.Win) << r;
       }
       const unsigned vm = ((hm & 1u) ? wmk : 0u) | ((hm & 2u) ? wmk << p.ks : 0u) | ((hm & 4u) ? wmk << (2 * p.ks) : 0u);
-      ri.mask = m < M ? vm : 0u;
+      ri.aux = m < M ? vm : 0u;
       ri.ptr = reinterpret_cast<const char*>(p.s0.ptr) +
                ((((long)b * p.s0.H + h0) * p.s0.W + w0) * (long)p.s0.cstride + p.s0.coff) * (long)sizeof(T);
     }
-    ri.pad = 0;
     rinfo[i] = ri;
   }
   // weights: Cout is a multiple of 256 here, every row exists; row n0 + prow + 64 i, advancing BK halfs per K tile
@@ -102,21 +108,22 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   // changes tap at the same tile
   int kc = 0, tap = 0;                                 // channel offset of the current tile inside its tap; tap index r * ks + s
   auto retarget = [&]() {
-    const int kr = tap / p.ks, ks_ = tap - kr * p.ks;
+    const int kr = a.two ? 0 : tap / p.ks, ks_ = a.two ? 0 : tap - kr * p.ks;
     const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc + chunk * E) * (long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const RowInfo ri = rinfo[i];
-      const bool ok = (ri.mask >> tap) & 1u;
-      if constexpr (BUF) cur32[i] = ok ? (unsigned)((ri.ptr + delta) - reinterpret_cast<const char*>(p.s0.ptr)) : 0xffffffffu;
-      else cur[i] = ok ? ri.ptr + delta : reinterpret_cast<const char*>(&g_zero16);
+      const bool ok = a.two ? ri.ptr != nullptr : (bool)((ri.aux >> tap) & 1u);
+      const char* src = (a.two && tap) ? reinterpret_cast<const char*>(ri.aux) : ri.ptr;   // two sources: `tap` counts the source
+      if constexpr (BUF) cur32[i] = ok ? (unsigned)((src + delta) - reinterpret_cast<const char*>(p.s0.ptr)) : 0xffffffffu;
+      else cur[i] = ok ? src + delta : reinterpret_cast<const char*>(&g_zero16);
       inc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
     }
   };
   retarget();
   auto advance_p = [&]() {
     kc += BK;
-    if (kc == p.Cin) { kc = 0; ++tap; retarget(); }
+    if (kc == (a.two ? (tap ? p.s1.C : p.s0.C) : p.Cin)) { kc = 0; ++tap; retarget(); }
     else {
 #pragma unroll
       for (int i = 0; i < XR; ++i) { if constexpr (BUF) cur32[i] += inc[i]; else cur[i] += inc[i]; }
@@ -300,7 +307,7 @@ template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, in
   const size_t xb = (size_t)p.B * p.s0.H * p.s0.W * p.s0.cstride * sizeof(T), wbytes = (size_t)p.Cout * p.Kw * sizeof(T);
   const bool buf_ok = xb < ((size_t)1 << 32) - 256 && wbytes < ((size_t)1 << 32) - 256;
   b.x_bytes = (unsigned)xb; b.w_bytes = (unsigned)wbytes;
-  if ((flags & 64) && buf_ok) { hipLaunchKernelGGL((conv_phase_kernel<T, 2>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b); return; }
+  if ((flags & 64) && buf_ok && !a.two) { hipLaunchKernelGGL((conv_phase_kernel<T, 2>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b); return; }
   if (flags & 32) hipLaunchKernelGGL((conv_phase_kernel<T, 1>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
   else hipLaunchKernelGGL((conv_phase_kernel<T, 0>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
 }
