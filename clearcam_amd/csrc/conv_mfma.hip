@@ -836,10 +836,10 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
       // CLEARCAM_PHASE=0 disables, 1 forces it for every eligible layer.
       const bool simple1 = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
       // one block of eight waves per CU vs two blocks of four with 128x128 tiles: whichever fills its last round of CUs better wins,
-      // the eight-wave kernel being ~12 % faster at equal fill (per-layer A/B, profiles/r02c_*)
+      // the eight-wave kernel being 12-20 % faster at equal fill (per-layer A/B, profiles/r02c_*)
       const long t128 = (long)((M + 127) / 128) * ((p.Cout + 127) / 128);
       const double fill256 = (double)tiles / (double)(rounds * 256), fill128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-      const bool phase_rule = tiles >= 128 && fill256 * 1.12 >= fill128;
+      const bool phase_rule = tiles >= 128 && fill256 * 1.2 >= fill128;
       // ... and the 1x1 convs that read a Concat (two sources, one possibly upsampled: the first conv of the neck's ELAN blocks)
       const bool concat1 = p.s1.C > 0 && p.ks == 1 && p.stride == 1 && p.pad == 0 && p.s0.C % 64 == 0 && p.s1.C % 64 == 0;
       use_two = concat1;

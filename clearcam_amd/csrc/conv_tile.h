@@ -16,6 +16,7 @@ struct ConvAux {
   int is1x1;              // 1x1, stride 1, no pad, no upsample: input pixel index == output pixel index
   int flags;              // tuning switches of conv_phase_kernel (CLEARCAM_PHASE_FLAGS)
   unsigned x_bytes, w_bytes;   // conv_phase_kernel with buffer-descriptor DMA: sizes of the input tensor and of the weights
+  int ntiles;             // conv_phase_persist_kernel: tiles in the layer
   int two;                // conv_phase_kernel: 1x1 conv over the channel concat of two sources (either may be read nearest-upsampled)
 };
 
