@@ -107,7 +107,7 @@ struct ConvP {
   const void* res; int res_cstride, res_coff; int res_f32;   // optional residual (same pixel grid as out)
   int act;                       // 0 none, 1 SiLU, 2 tanh-GELU, 3 PReLU (x > 0 ? x : slope[channel] * x), 4 ReLU applied AFTER the residual add
   const float* slope;            // [Cout] PReLU slopes (act 3), else null
-  int variant;                   // kernel choice: 0 auto; tests force 1 direct, 2 generic MFMA, 3 halo-resident 3x3, 4 weights-stationary 3x3, 5 single-barrier schedule with 256x256 tiles, 6 the same with 128x128 tiles, 7 eight-wave two-group 256x256 kernel, 8 wave-autonomous narrow 3x3
+  int variant;                   // kernel choice: 0 auto; tests force 1 direct, 2 generic MFMA, 3 halo-resident 3x3, 4 weights-stationary 3x3, 5 single-barrier schedule with 256x256 tiles, 6 the same with 128x128 tiles, 7 eight-wave two-group 256x256 kernel, 8 wave-autonomous narrow 3x3, 9 few-tile configuration (narrow channel tiles, 3-4 LDS stages)
 };
 
 // Plan cache of a model handle: one plan (buffers + captured hipGraph) per input shape, bounded.  A service that sees many

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
   static_assert(BN % RPP == 0, "BN too small for this row width");
   static_assert(NS * STAGE * 16 >= BM * BN * 2, "epilogue tile must fit in the stages");
   static_assert(MI >= 1 && NJ >= 1, "bad wave layout");
+  static_assert((NS - 2) * LPS < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // NS stages; the first BM*BN*2 bytes double as the epilogue tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -186,7 +187,9 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
   for (int kt = 0; kt < nkt; ++kt) {
     // step kt must have landed; later steps (at most NS-2 of them) may stay in flight
     const int ahead = issued - kt - 1;
-    if (NS > 3 && ahead >= 2) wait_vmcnt<2 * LPS>();
+    if (NS > 5 && ahead >= 4) wait_vmcnt<4 * LPS>();
+    else if (NS > 4 && ahead >= 3) wait_vmcnt<3 * LPS>();
+    else if (NS > 3 && ahead >= 2) wait_vmcnt<2 * LPS>();
     else if (NS > 2 && ahead >= 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __syncthreads();                                   // ... for every wave; the stage consumed at step kt-1 is free again
@@ -783,9 +786,41 @@ template <class T> static void launch_ws_t(const ConvP& p, hipStream_t stream) {
   else { if (p.Cout > 32) launch_ws<T, 32, 64>(p, stream); else launch_ws<T, 32, 32>(p, stream); }
 }
 
+static bool halo_applicable(const ConvP& p);
+
+// Few-tile layers (a single frame, or the 20x20 maps of a batch): the grid does not fill the chip, one block per CU at best, and a
+// K step is then paced by the round trip of the DMA issued one step earlier (~0.6 us per step measured at batch 1: a 36-step 3x3
+// 256 -> 256 layer took 31 us on 8 blocks).  Here the generic kernel runs with narrow channel tiles (more blocks -> more CUs) and
+// three to six LDS stages (prefetch distance two to five steps: the queue is never drained, counted vmcnt only), which is
+// what the otherwise idle LDS is for.  CLEARCAM_SMALL_TILES=0 disables; tests force it with variant 9.
+template <class T> static bool launch_small(const ConvP& p, int M, hipStream_t stream, bool force) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CLEARCAM_SMALL_TILES"); on = e ? atoi(e) : 1; }
+  if (!force && !on) return false;
+  const long mt = (M + 127) / 128, b32 = mt * ((p.Cout + 31) / 32), b64 = mt * ((p.Cout + 63) / 64);
+  int bn = 0;
+  if (b32 <= 512) bn = 32; else if (b64 <= 512) bn = 64;
+  if (force && !bn) bn = 64;
+  if (!bn) return false;
+  const bool deep = bn == 32 && b32 <= 256;            // at most one block per CU anyway: six stages (120 KB), prefetch distance five
+  ConvAux a{};
+  a.nt = (p.Cout + bn - 1) / bn;
+  a.inv_hw = 1.0f / (float)(p.Ho * p.Wo); a.inv_wo = 1.0f / (float)p.Wo;
+  const bool simple = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
+  a.is1x1 = simple && p.ks == 1 && p.stride == 1 && p.pad == 0 && p.Hin == p.Ho && p.Win == p.Wo;
+  if (deep) { if (simple) launch_k<T, 128, 32, 4, true, 8, 6>(p, a, (int)mt, stream); else launch_k<T, 128, 32, 4, false, 8, 6>(p, a, (int)mt, stream); }
+  else if (bn == 32) { if (simple) launch_k<T, 128, 32, 4, true, 8, 4>(p, a, (int)mt, stream); else launch_k<T, 128, 32, 4, false, 8, 4>(p, a, (int)mt, stream); }
+  else { if (simple) launch_k<T, 128, 64, 2, true, 8, 3>(p, a, (int)mt, stream); else launch_k<T, 128, 64, 2, false, 8, 3>(p, a, (int)mt, stream); }
+  CC_HIP(hipGetLastError());
+  return true;
+}
+
 template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   const int M = p.B * p.Ho * p.Wo;
   if constexpr (sizeof(T) == 2) {
+    // (layers the halo-resident kernel takes at any batch size keep it: its K order is (channel slab, tap), every other kernel's
+    //  (tap, channel), and a frame's result must not depend on the batch it arrives in - test_batch_invariance_and_determinism)
+    if (((p.variant == 0 && !halo_applicable(p)) || p.variant == 9) && launch_small<T>(p, M, stream, p.variant == 9)) return;
     {   // narrow 3x3 layers: one autonomous wave per 2x16-pixel sub-tile over LDS-resident weights (conv_wave.hip).
         // CLEARCAM_WAVE=0 falls back to the cooperative kernels below; tests force it with variant 8.
       static int wave_on = -1;

@@ -1,0 +1,449 @@
+// RepNCSP (detection/yolov9.py:92-105) as ONE kernel for the narrow levels of the detector (hidden width 32 or 64):
+//
+//     a = SiLU(cv1 x)            1x1, 2*HID -> HID          b = SiLU(cv2 x)      1x1, 2*HID -> HID
+//     t = SiLU(rep3x3 a)         RepConvN folded to one 3x3 (yolov9.py:82-90), HID -> HID
+//     u = a + SiLU(conv3x3 t)    RepNBottleneck's second conv + shortcut
+//     out = SiLU(cv3 [u | b])    1x1, 2*HID -> 2*HID
+//
+// Layer at a time these are four launches that move x, [a|b], t, u and out through HBM (544 channel-pixels per pixel at
+// HID = 32 against 128 for x in / out out) and run at 150-550 TFLOP/s because every one of them is a few tiny K steps
+// (profiles/r02c_yolo_per_launch.csv, ops 3-6 and 19-22).  Here a block of eight waves owns an 8 x 16-pixel output tile and
+// keeps every intermediate in LDS:
+//     X   the 12 x 20 input patch (halo 2), DMA'd once, 64-channel slabs of 128-byte rows (chunk-swizzled like every tile)
+//     A   cv1 output on the whole patch (zero outside the image: it is the zero padding of the 3x3 that reads it)
+//     B   cv2 output on the 8 x 16 inner pixels
+//     T   first 3x3 on the 10 x 18 ring (halo 1; zero outside the image), aliasing X
+//     U   second 3x3 + a (inner pixels), aliasing X behind T
+// The recompute on the halo is 14 % of the block's MACs (cv1 on 240 instead of 128 pixels, the first 3x3 on 180).
+// Every intermediate is rounded to the storage type exactly where the layer-at-a-time path stores it and the K order of every
+// accumulation is the same, so the result is bit-identical to the four launches it replaces
+// (tests/test_gpu_yolo.py::test_fused_csp_equals_unfused).
+//
+// Two variants of the outer loop:
+//   RES = true  (HID 32: 56 KB of weights): PERSISTENT blocks, one per CU; the four weight matrices are loaded once and stay in
+//               LDS, the input patch is double-buffered (the patch of the next tile streams in under the current tile), so a
+//               tile is four stage barriers and no exposed DMA wait; biases sit in LDS too (no global load in the loop).
+//   RES = false (HID 64: 208 KB of weights cannot stay): one tile per block; weights stream from L2 in chunks of one to three
+//               64-wide K slabs through a two-slot ring, chunk i+1 issued at the barrier that opens chunk i.  Measured slower than
+//               the four launches at HID 64 (every chunk waits a full L2 round trip behind ~0.3 us of MFMA work), so the graph
+//               builder only takes it on request (CLEARCAM_FUSE_CSP=2).
+#include <utility>
+#include "conv_tile.h"
+
+namespace cc {
+
+template <int V> using IC = std::integral_constant<int, V>;
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(IC<I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <int HID> struct CspGeom {
+  static constexpr int C2 = 2 * HID, NSLAB = C2 / 64;                        // X / cv1|cv2 / cv3 K slabs of 64 channels
+  static constexpr int TH = 8, TW = 16, PW = TW + 4, PH = TH + 4, PR = PH * PW;   // 12 x 20 = 240 patch pixels
+  static constexpr int QW = TW + 2, QH = TH + 2, QR = QH * QW;               // 10 x 18 = 180 ring pixels
+  static constexpr int CPA = HID / 8;                                        // 16-byte chunks per row of A, B, T, U
+  // Row pitch of the intermediates: HID channels + 16 bytes of padding.  They are written by ds_write (not by the lane-linear
+  // DMA), so their layout is free: with a pitch of 20 (36) dwords sixteen consecutive rows start on sixteen different 4-bank
+  // groups - conflict-free fragment reads without an XOR swizzle, i.e. every tap of a 3x3 is base + compile-time offset.
+  static constexpr int PA = HID * 2 + 16;
+  static constexpr int X_BYTES = NSLAB * PR * 128, A_BYTES = 256 * PA, B_BYTES = 128 * PA, T_BYTES = 192 * PA, U_BYTES = 128 * PA;
+  static constexpr int BIAS_BYTES = (2 * C2 + 2 * HID) * 4;                  // b12 | br | bb | b3 as f32
+  static constexpr int SPC = HID == 64 ? 2 : 3;                              // streaming: 3x3 weight slabs per chunk
+  static constexpr int NS3 = (9 * HID + 63) / 64, NC3 = (NS3 + SPC - 1) / SPC;   // slabs / chunks per 3x3 stage: 9 / 5 and 5 / 2
+  static constexpr int SLAB_BIG = C2 * 128, SLAB_SMALL = HID * 128;          // bytes of a 64-wide K slab of cv1|cv2 / cv3 and of a 3x3
+  static constexpr int RING = SLAB_BIG > SPC * SLAB_SMALL ? SLAB_BIG : SPC * SLAB_SMALL;
+  static constexpr int NCHUNK = 2 * NSLAB + 2 * NC3;
+  // streaming layout: patch | A | B | two ring slots
+  static constexpr int S_OFF_A = X_BYTES, S_OFF_B = S_OFF_A + A_BYTES, S_OFF_R = S_OFF_B + B_BYTES, S_OFF_BIAS = S_OFF_R + 2 * RING,
+                       S_LDS_BYTES = (S_OFF_BIAS + BIAS_BYTES + 2047) & ~2047;
+  // (sizes are rounded up to 2 KB: the tail of a dynamic-LDS request that is not a whole number of allocation granules is not
+  //  addressable - reads of the last 256 bytes of a 150,272-byte request faulted on MI355X)
+  // resident layout: two patch buffers | A | B | cv1|cv2 | rep 3x3 | 3x3 | cv3, slab by slab
+  static constexpr int R_OFF_A = 2 * X_BYTES, R_OFF_B = R_OFF_A + A_BYTES, R_OFF_W12 = R_OFF_B + B_BYTES, R_OFF_WR = R_OFF_W12 + NSLAB * SLAB_BIG,
+                       R_OFF_WB = R_OFF_WR + NS3 * SLAB_SMALL, R_OFF_W3 = R_OFF_WB + NS3 * SLAB_SMALL, R_OFF_BIAS = R_OFF_W3 + NSLAB * SLAB_BIG,
+                       R_LDS_BYTES = (R_OFF_BIAS + BIAS_BYTES + 2047) & ~2047;
+  static_assert(T_BYTES + U_BYTES <= X_BYTES, "T and U alias the input patch");
+};
+
+template <class T, int HID, bool RES>
+__global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
+  using G = CspGeom<HID>;
+  constexpr int C2 = G::C2, NSLAB = G::NSLAB, PW = G::PW, PR = G::PR, QW = G::QW, QR = G::QR, CPA = G::CPA, PA = G::PA;
+  constexpr int NJ1 = C2 / 16, NJ2 = HID / 32, NJ4 = HID / 16, SPC = G::SPC, NS3 = G::NS3, NC3 = G::NC3;
+  constexpr int OFF_A = RES ? G::R_OFF_A : G::S_OFF_A, OFF_B = RES ? G::R_OFF_B : G::S_OFF_B, OFF_BIAS = RES ? G::R_OFF_BIAS : G::S_OFF_BIAS;
+  constexpr int BI_12 = OFF_BIAS, BI_R = BI_12 + C2 * 4, BI_B = BI_R + HID * 4, BI_3 = BI_B + HID * 4;
+  static_assert(sizeof(T) == 2 && (HID == 32 || HID == 64), "16-bit storage, hidden width 32 or 64");
+  static_assert(!RES || G::R_LDS_BYTES <= 160 * 1024, "resident weights do not fit");
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const unsigned lds_base = lds_addr(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int pg = wave & 3, chh = wave >> 2;                        // stages 2-4: pixel group / channel half of this wave
+  const int total = p.B * p.tiles;
+
+  // ---- tile walk: consecutive tiles (neighbours share halo pixels) stay on one XCD's L2 ---------------------------------------
+  // one tile per block (streaming): the bijective blockIdx remap of the conv kernels; persistent: XCD x owns a contiguous range
+  // of tiles and its blocks (blockIdx % 8 == x) walk it with stride gridDim / 8
+  int tile, tile_end, tile_step;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    if constexpr (RES) {
+      const int q = total >> 3, r = total & 7;
+      const int start = xcd * q + (xcd < r ? xcd : r);
+      tile = start + idx; tile_end = start + q + (xcd < r ? 1 : 0); tile_step = nwg >> 3;
+    } else {
+      const int q = nwg >> 3, r = nwg & 7;
+      tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; tile_end = tile + 1; tile_step = 1;
+    }
+  }
+  int b = 0, h0 = 0, w0 = 0;                                       // current tile: image, top-left output pixel
+  auto in_image = [&](int ih, int iw) { return (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W; };
+
+  // ---- DMA ---------------------------------------------------------------------------------------------------------------------
+  auto issue_x = [&](int t, int x_off) {                           // the 12 x 20 input patch of tile t
+    const int tb = fdiv(t, p.tiles, p.inv_tiles), trem = t - tb * p.tiles, ty = fdiv(trem, p.tx, p.inv_tx), tx = trem - ty * p.tx;
+    const int th0 = ty * G::TH, tw0 = tx * G::TW;
+    constexpr int XPIECES = NSLAB * (PR / 8);                      // 1 KiB pieces: 8 patch rows x 128 bytes
+#pragma unroll
+    for (int i = 0; i < (XPIECES + 7) / 8; ++i) {
+      const int pi = wave + 8 * i;
+      if (pi < XPIECES) {
+        const int sl = pi / (PR / 8), rg = pi - sl * (PR / 8);
+        const int row = rg * 8 + (lane >> 3), pos = lane & 7;
+        const int py = row / PW, px = row - py * PW;
+        const int ih = th0 - 2 + py, iw = tw0 - 2 + px;
+        const int chunk = pos ^ swz<8>(row);
+        const void* src = in_image(ih, iw)
+            ? static_cast<const void*>(reinterpret_cast<const char*>(p.x) + ((((long)tb * p.H + ih) * p.W + iw) * (long)p.x_cstride + p.x_coff + sl * 64 + chunk * 8) * 2L)
+            : static_cast<const void*>(&g_zero16);
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(x_off + sl * (PR * 128) + rg * 1024)));
+      }
+    }
+  };
+  // rows [0, NR) x 64 k of slabs slab0 .. slab0+NSL-1 of a [rows][kw] weight matrix -> LDS at dst_off, [slab][row][128 B] swizzled by row
+  auto issue_w = [&](const void* wbase, int kw, auto nr_c, int slab0, auto nsl_c, unsigned dst_off) {
+    constexpr int NR = decltype(nr_c)::value, NSL = decltype(nsl_c)::value, PPS = NR / 8, PIECES = NSL * PPS;
+#pragma unroll
+    for (int i = 0; i < (PIECES + 7) / 8; ++i) {
+      const int pi = wave + 8 * i;
+      if (pi < PIECES) {
+        const int sl = pi / PPS, rg = pi - sl * PPS;
+        const int n = rg * 8 + (lane >> 3), pos = lane & 7;
+        const int chunk = pos ^ swz<8>(n);
+        const char* src = reinterpret_cast<const char*>(wbase) + ((size_t)n * kw + (size_t)(slab0 + sl) * 64 + chunk * 8) * 2;
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_base + dst_off + (unsigned)(sl * (NR * 128) + rg * 1024)));
+      }
+    }
+  };
+  // streaming: chunk K of the tile's weight stream goes to ring slot K & 1
+  auto issue_chunk = [&](auto k_c) {
+    constexpr int K = decltype(k_c)::value;
+    constexpr unsigned dst = G::S_OFF_R + (K & 1) * G::RING;
+    if constexpr (K < NSLAB) issue_w(p.w12, p.kw12, IC<C2>{}, K, IC<1>{}, dst);
+    else if constexpr (K < NSLAB + NC3) { constexpr int s0 = (K - NSLAB) * SPC; issue_w(p.wr, p.kwr, IC<HID>{}, s0, IC<(NS3 - s0 < SPC ? NS3 - s0 : SPC)>{}, dst); }
+    else if constexpr (K < NSLAB + 2 * NC3) { constexpr int s0 = (K - NSLAB - NC3) * SPC; issue_w(p.wb, p.kwb, IC<HID>{}, s0, IC<(NS3 - s0 < SPC ? NS3 - s0 : SPC)>{}, dst); }
+    else if constexpr (K < G::NCHUNK) issue_w(p.w3, p.kw3, IC<C2>{}, K - NSLAB - 2 * NC3, IC<1>{}, dst);
+  };
+  // Opens K slab SL of stage ST (0 cv1|cv2, 1 rep 3x3, 2 3x3, 3 cv3) and returns its LDS byte offset.
+  // Streaming: at the first slab of a chunk wait for it, barrier (everything written to LDS before is visible, the other ring slot is
+  // free again) and issue the next chunk.  Resident: a barrier at the first slab of a stage (the previous stage's LDS writes).
+  // Stage 0 slab 0 is opened by the tile loop itself.
+  auto open_slab = [&](auto st_c, auto sl_c) -> int {
+    constexpr int ST = decltype(st_c)::value, SL = decltype(sl_c)::value;
+    if constexpr (RES) {
+      if constexpr (SL == 0 && ST == 3) wait_vmcnt<0>();           // the next tile's patch (issued a whole tile ago) has landed
+      if constexpr (SL == 0 && ST > 0) __syncthreads();
+      return ST == 0 ? G::R_OFF_W12 + SL * G::SLAB_BIG : ST == 1 ? G::R_OFF_WR + SL * G::SLAB_SMALL : ST == 2 ? G::R_OFF_WB + SL * G::SLAB_SMALL : G::R_OFF_W3 + SL * G::SLAB_BIG;
+    } else {
+      constexpr bool big = ST == 0 || ST == 3;
+      constexpr int K = ST == 0 ? SL : ST == 1 ? NSLAB + SL / SPC : ST == 2 ? NSLAB + NC3 + SL / SPC : NSLAB + 2 * NC3 + SL;
+      constexpr int within = big ? 0 : (SL % SPC) * G::SLAB_SMALL;
+      if constexpr ((big || SL % SPC == 0) && K > 0) { wait_vmcnt<0>(); __syncthreads(); issue_chunk(IC<K + 1>{}); }
+      return G::S_OFF_R + (K & 1) * G::RING + within;
+    }
+  };
+  // bias + SiLU of one accumulator fragment -> four storage-type values (8 bytes); `keep` false -> zeros (outside the image)
+  auto act4 = [&](const f32x4& av, int bias_off, bool keep) {
+    const float4 b4 = *reinterpret_cast<const float4*>(ldsb + bias_off);
+    uint2 pk = make_uint2(pack2<T>(activate<T, 1>(av[0] + b4.x), activate<T, 1>(av[1] + b4.y)), pack2<T>(activate<T, 1>(av[2] + b4.z), activate<T, 1>(av[3] + b4.w)));
+    if (!keep) pk = make_uint2(0u, 0u);
+    return pk;
+  };
+  // row-major [rows][PA] intermediates: byte offset of channel n of row `row`
+  auto elem_off = [&](int region, int row, int n) { return region + row * PA + n * 2; };
+  auto out_pix = [&](int q) {
+    const int ho = h0 + (q >> 4), wo = w0 + (q & 15);
+    return (ho < p.H && wo < p.W) ? ((long)b * p.H + ho) * p.W + wo : -1L;
+  };
+  // development: copy an intermediate (inner 8 x 16 pixels) to the output view instead of finishing the block
+  auto dump = [&](int region, auto rowfn, int ch_off) {
+    for (int idx = tid; idx < 128 * CPA; idx += 512) {
+      const int q = idx / CPA, ch = idx - q * CPA, row = rowfn(q);
+      const uint4 v = *reinterpret_cast<const uint4*>(ldsb + region + row * PA + ch * 16);
+      const long m = out_pix(q);
+      if (m >= 0) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + ch_off + ch * 8) = v;
+    }
+  };
+  // 3x3 over an LDS-resident map: pixel fragment i reads 16 bytes at fp[i] + (r * SRCW + s) * PA (+ 64 for the second K half at
+  // HID 64): one base pointer per fragment, every tap a compile-time offset.  K slab J of the stage's weights at woff.
+  auto conv3_slab = [&](auto j_c, int woff, auto npx_c, auto srcw_c, const auto& fp, auto& acc) {
+    constexpr int J = decltype(j_c)::value, NPX = decltype(npx_c)::value, SRCW = decltype(srcw_c)::value;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const int tap = HID == 64 ? J : 2 * J + kh;                  // a 64-wide K slab is one tap (HID 64) or two (HID 32)
+      if (tap < 9) {
+        const int r = tap / 3, s = tap - r * 3;
+        uint4 xf[NPX], wf[NJ2];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) xf[i] = *reinterpret_cast<const uint4*>(fp[i] + (r * SRCW + s) * PA + (HID == 64 ? kh * 64 : 0));
+#pragma unroll
+        for (int jj = 0; jj < NJ2; ++jj) { const int n = (chh * NJ2 + jj) * 16 + fr; wf[jj] = *reinterpret_cast<const uint4*>(ldsb + woff + n * 128 + (((kh * 4 + fg) ^ swz<8>(n)) << 4)); }
+#pragma unroll
+        for (int jj = 0; jj < NJ2; ++jj)
+#pragma unroll
+          for (int i = 0; i < NPX; ++i) Mma<T>::run(wf[jj], xf[i], acc[jj][i]);
+      }
+    }
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------------------------------------------
+  int x_off = 0;                                                   // byte offset of the current tile's patch (T and U alias it)
+  if (tid < G::BIAS_BYTES / 4 && !(p.dbg & 1024)) {                // the four bias vectors -> LDS (published by the first barrier)
+    const float* src = tid < C2 ? p.b12 + tid : tid < C2 + HID ? p.br + (tid - C2) : tid < C2 + 2 * HID ? p.bb + (tid - C2 - HID) : p.b3 + (tid - C2 - 2 * HID);
+    reinterpret_cast<float*>(ldsb + OFF_BIAS)[tid] = *src;
+  }
+  if (p.dbg & 4096) return;
+  if (tile < tile_end) issue_x(tile, 0);
+  if constexpr (RES) {
+    issue_w(p.w12, p.kw12, IC<C2>{}, 0, IC<NSLAB>{}, G::R_OFF_W12);
+    issue_w(p.wr, p.kwr, IC<HID>{}, 0, IC<NS3>{}, G::R_OFF_WR);
+    issue_w(p.wb, p.kwb, IC<HID>{}, 0, IC<NS3>{}, G::R_OFF_WB);
+    issue_w(p.w3, p.kw3, IC<C2>{}, 0, IC<NSLAB>{}, G::R_OFF_W3);
+  } else {
+    issue_chunk(IC<0>{});
+  }
+
+  wait_vmcnt<0>();                                                 // first patch, resident weights / first chunk
+  if (p.dbg & 2048) return;
+  for (; tile < tile_end; tile += tile_step) {
+    {
+      b = fdiv(tile, p.tiles, p.inv_tiles);
+      const int trem = tile - b * p.tiles, ty = fdiv(trem, p.tx, p.inv_tx), tx = trem - ty * p.tx;
+      h0 = ty * G::TH; w0 = tx * G::TW;
+    }
+    const int off_t = x_off, off_u = x_off + G::T_BYTES;
+    // every wave is done with the previous tile (its staging copy-out out of A, its reads of B and U) and the other patch buffer is
+    // free.  This tile's patch has landed: the first one was waited for above, later ones at the opening of the previous tile's
+    // stage 4 - so that the previous tile's output stores are NOT waited for here and drain under this tile.
+    if (p.dbg & 256) wait_vmcnt<0>();
+    __syncthreads();
+    if constexpr (RES) { if (tile + tile_step < tile_end) issue_x(tile + tile_step, G::X_BYTES - x_off); }
+    else issue_chunk(IC<1>{});
+
+    // ---- stage 1: [a | b] = SiLU(W12 x + b12); wave w owns patch-pixel fragments w and w + 8, all 2*HID channels ---------------
+    {
+      f32x4 acc[NJ1][2];
+#pragma unroll
+      for (int j = 0; j < NJ1; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      int xrow[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const int row = 16 * (wave + 8 * i) + fr; xrow[i] = row < PR ? row : PR - 1; }   // fragment 15 is half empty: clamp
+      static_for<NSLAB>([&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        const int woff = open_slab(IC<0>{}, IC<S>{});
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          uint4 xf[2], wf[NJ1];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const uint4*>(ldsb + x_off + S * (PR * 128) + xrow[i] * 128 + (((kh * 4 + fg) ^ swz<8>(xrow[i])) << 4));
+#pragma unroll
+          for (int j = 0; j < NJ1; ++j) { const int n = 16 * j + fr; wf[j] = *reinterpret_cast<const uint4*>(ldsb + woff + n * 128 + (((kh * 4 + fg) ^ swz<8>(n)) << 4)); }
+#pragma unroll
+          for (int j = 0; j < NJ1; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+        }
+      });
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 16 * (wave + 8 * i) + fr;                  // rows 240..255 land in A's padding and are never read
+        const int py = row / PW, px = row - py * PW;
+        const bool inimg = in_image(h0 - 2 + py, w0 - 2 + px);
+        const bool inner = py >= 2 && py < 2 + G::TH && px >= 2 && px < 2 + G::TW;
+        const int q = (py - 2) * G::TW + (px - 2);
+#pragma unroll
+        for (int j = 0; j < NJ1; ++j) {
+          const int n = 16 * j + 4 * fg;
+          if (j < HID / 16) *reinterpret_cast<uint2*>(ldsb + elem_off(OFF_A, row, n)) = act4(acc[j][i], BI_12 + n * 4, inimg);
+          else if (inner) *reinterpret_cast<uint2*>(ldsb + elem_off(OFF_B, q, n - HID)) = act4(acc[j][i], BI_12 + n * 4, true);
+        }
+      }
+    }
+    if (p.dbg == 1) {
+      wait_vmcnt<0>(); __syncthreads();
+      dump(OFF_A, [](int q) { return ((q >> 4) + 2) * PW + (q & 15) + 2; }, 0);
+      dump(OFF_B, [](int q) { return q; }, HID);
+      if constexpr (RES) { x_off = G::X_BYTES - x_off; continue; } else return;
+    }
+
+    // ---- stage 2: t = SiLU(Wr * a + br) on the 10 x 18 ring; wave = (pixel fragments 3pg..3pg+2) x (channel half chh) ------------
+    {
+      f32x4 acc[NJ2][3];
+      const char* fp[3]; int qq[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        qq[i] = 16 * (3 * pg + i) + fr;
+        const int qc = qq[i] < QR ? qq[i] : QR - 1;
+        const int ty_ = qc / QW, tx_ = qc - ty_ * QW;
+        fp[i] = ldsb + OFF_A + (ty_ * PW + tx_) * PA + fg * 16;
+#pragma unroll
+        for (int jj = 0; jj < NJ2; ++jj) acc[jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      static_for<NS3>([&](auto j_c) {
+        const int woff = open_slab(IC<1>{}, j_c);
+        conv3_slab(j_c, woff, IC<3>{}, IC<PW>{}, fp, acc);
+      });
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int q = qq[i];
+        if (q < QR) {
+          const int ty_ = q / QW, tx_ = q - ty_ * QW;
+          const bool inimg = in_image(h0 - 1 + ty_, w0 - 1 + tx_);
+#pragma unroll
+          for (int jj = 0; jj < NJ2; ++jj) {
+            const int n = (chh * NJ2 + jj) * 16 + 4 * fg;
+            *reinterpret_cast<uint2*>(ldsb + elem_off(off_t, q, n)) = act4(acc[jj][i], BI_R + n * 4, inimg);
+          }
+        }
+      }
+    }
+    if (p.dbg == 2) {
+      wait_vmcnt<0>(); __syncthreads();
+      dump(off_t, [](int q) { return ((q >> 4) + 1) * QW + (q & 15) + 1; }, 0);
+      if constexpr (RES) { x_off = G::X_BYTES - x_off; continue; } else return;
+    }
+
+    // ---- stage 3: u = a + SiLU(Wb * t + bb) on the 8 x 16 inner pixels; wave = (output rows 2pg, 2pg+1) x (channel half) ----------
+    {
+      f32x4 acc[NJ2][2];
+      const char* fp[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fp[i] = ldsb + off_t + ((2 * pg + i) * QW + fr) * PA + fg * 16;
+#pragma unroll
+        for (int jj = 0; jj < NJ2; ++jj) acc[jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      static_for<NS3>([&](auto j_c) {
+        const int woff = open_slab(IC<2>{}, j_c);
+        conv3_slab(j_c, woff, IC<2>{}, IC<QW>{}, fp, acc);
+      });
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int oy = 2 * pg + i, q = 16 * oy + fr, arow = (oy + 2) * PW + fr + 2;
+#pragma unroll
+        for (int jj = 0; jj < NJ2; ++jj) {
+          const int n = (chh * NJ2 + jj) * 16 + 4 * fg;
+          const float4 b4 = *reinterpret_cast<const float4*>(ldsb + BI_B + n * 4);
+          const f32x4 av = acc[jj][i];
+          const uint2 ru = *reinterpret_cast<const uint2*>(ldsb + elem_off(OFF_A, arow, n));
+          const T* rt = reinterpret_cast<const T*>(&ru);
+          *reinterpret_cast<uint2*>(ldsb + elem_off(off_u, q, n)) =
+              make_uint2(pack2<T>(to_f32<T>(rt[0]) + activate<T, 1>(av[0] + b4.x), to_f32<T>(rt[1]) + activate<T, 1>(av[1] + b4.y)),
+                         pack2<T>(to_f32<T>(rt[2]) + activate<T, 1>(av[2] + b4.z), to_f32<T>(rt[3]) + activate<T, 1>(av[3] + b4.w)));
+        }
+      }
+    }
+    if (p.dbg == 3) {
+      wait_vmcnt<0>(); __syncthreads();
+      dump(off_u, [](int q) { return q; }, 0);
+      dump(OFF_B, [](int q) { return q; }, HID);
+      if constexpr (RES) { x_off = G::X_BYTES - x_off; continue; } else return;
+    }
+
+    // ---- stage 4: out = SiLU(W3 [u | b] + b3); wave = (pixel fragments 2pg, 2pg+1) x (channels chh*HID .. +HID) -------------------
+    f32x4 acc4[NJ4][2];
+#pragma unroll
+    for (int jj = 0; jj < NJ4; ++jj) { acc4[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc4[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    static_for<NSLAB>([&](auto s_c) {
+      constexpr int S = decltype(s_c)::value;
+      const int woff = open_slab(IC<3>{}, s_c);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const int region = (HID == 64 ? S : kh) == 0 ? off_u : OFF_B;          // K order of cv3: the m-branch channels, then cv2's
+        const int pc = HID == 64 ? kh * 4 + fg : fg;
+        uint4 xf[2], wf[NJ4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int q = 16 * (2 * pg + i) + fr; xf[i] = *reinterpret_cast<const uint4*>(ldsb + region + q * PA + pc * 16); }
+#pragma unroll
+        for (int jj = 0; jj < NJ4; ++jj) { const int n = chh * HID + 16 * jj + fr; wf[jj] = *reinterpret_cast<const uint4*>(ldsb + woff + n * 128 + (((kh * 4 + fg) ^ swz<8>(n)) << 4)); }
+#pragma unroll
+        for (int jj = 0; jj < NJ4; ++jj)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) Mma<T>::run(wf[jj], xf[i], acc4[jj][i]);
+      }
+    });
+    // bias + SiLU, then through A's bytes (free since the barrier that opened stage 4: its last reader was stage 3's shortcut) so
+    // that every pixel's 2*HID channels leave as 16-byte-per-lane, line-contiguous stores.  Padded rows, no swizzle.
+    {
+      constexpr int OROW = C2 * 2 + 16, OCPR = C2 / 8;             // staging row pitch (bytes), 16-byte chunks per pixel
+      static_assert(128 * OROW <= G::A_BYTES, "the output staging tile aliases A");
+      char* tilep = ldsb + OFF_A;
+#pragma unroll
+      for (int jj = 0; jj < NJ4; ++jj) {
+        const int nl = chh * HID + 16 * jj + 4 * fg;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          *reinterpret_cast<uint2*>(tilep + (32 * pg + 16 * i + fr) * OROW + nl * 2) = act4(acc4[jj][i], BI_3 + nl * 4, true);
+      }
+      __syncthreads();
+      T* outp = reinterpret_cast<T*>(p.out) + p.out_coff;
+#pragma unroll
+      for (int it = 0; it < 128 * OCPR / 512; ++it) {
+        const int idx = tid + 512 * it, row = idx / OCPR, ch = idx - row * OCPR;
+        const long m = out_pix(row);
+        if (m >= 0) *reinterpret_cast<uint4*>(outp + m * p.out_cstride + ch * 8) = *reinterpret_cast<const uint4*>(tilep + row * OROW + ch * 16);
+      }
+    }
+    if constexpr (RES) x_off = G::X_BYTES - x_off;
+  }
+}
+
+bool csp_fused_supported(int dt, int hid) { return (dt == F16 || dt == BF16) && (hid == 32 || hid == 64); }
+
+template <class T, int HID, bool RES> static void launch_csp(const CspP& p, hipStream_t stream) {
+  constexpr int lds = RES ? CspGeom<HID>::R_LDS_BYTES : CspGeom<HID>::S_LDS_BYTES;
+  static int cus = 0;
+  if (!cus) {
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csp_fused_kernel<T, HID, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    int dev = 0; hipDeviceProp_t pr;
+    CC_HIP(hipGetDevice(&dev)); CC_HIP(hipGetDeviceProperties(&pr, dev));
+    cus = pr.multiProcessorCount;
+  }
+  const int total = p.B * p.tiles;
+  // persistent: one block per CU, a multiple of 8 so that every XCD gets the same number of walkers
+  const int grid = RES ? std::max(8, std::min(cus, total) & ~7) : total;
+  hipLaunchKernelGGL((csp_fused_kernel<T, HID, RES>), dim3(grid), dim3(512), lds, stream, p);
+}
+
+void launch_csp_fused(int dt, const CspP& p0, hipStream_t stream) {
+  CC_CHECK(csp_fused_supported(dt, p0.hid), "fused RepNCSP: 16-bit storage and hidden width 32 or 64 only");
+  CC_CHECK(p0.x_cstride % 8 == 0 && p0.x_coff % 8 == 0 && p0.out_cstride % 8 == 0 && p0.out_coff % 8 == 0 && (((uintptr_t)p0.x | (uintptr_t)p0.out) & 15) == 0,
+           "fused RepNCSP: views must be 16-byte aligned");
+  CC_CHECK(p0.kw12 % 64 == 0 && p0.kw3 % 64 == 0 && p0.kwr % 64 == 0 && p0.kwb % 64 == 0 && p0.kwr >= 9 * p0.hid && p0.kwb >= 9 * p0.hid, "fused RepNCSP: weight rows must cover whole K slabs");
+  CspP p = p0;
+  p.tx = (p.W + 15) / 16; p.tiles = ((p.H + 7) / 8) * p.tx;
+  p.inv_tiles = 1.0f / (float)p.tiles; p.inv_tx = 1.0f / (float)p.tx;
+  CC_CHECK((long)p.B * p.tiles < (1L << 22), "fused RepNCSP: too many tiles");
+  const bool res = p.hid == 32 && !p.stream;                        // 56 KB of weights stay in LDS; 208 KB (hidden 64) cannot
+  if (dt == F16) {
+    if (p.hid == 64) launch_csp<f16_t, 64, false>(p, stream);
+    else if (res) launch_csp<f16_t, 32, true>(p, stream); else launch_csp<f16_t, 32, false>(p, stream);
+  } else {
+    if (p.hid == 64) launch_csp<bf16_t, 64, false>(p, stream);
+    else if (res) launch_csp<bf16_t, 32, true>(p, stream); else launch_csp<bf16_t, 32, false>(p, stream);
+  }
+  CC_HIP(hipGetLastError());
+}
+
+}  // namespace cc

@@ -14,6 +14,24 @@ void launch_conv_direct(int dt, const ConvP& p, hipStream_t stream);
 // Picks the MFMA kernel when supported, else the direct kernel.
 void launch_conv(int dt, const ConvP& p, hipStream_t stream);
 
+// ---- fused RepNCSP block (csp_fused.hip) ----------------------------------------------------------
+// detection/yolov9.py:92-105 with n = 1: cv1 | cv2 (1x1), RepConvN 3x3, 3x3 + shortcut, cv3 (1x1) in one launch; 16-bit
+// storage, hidden width 32 or 64.  Weights are the packed [Cout][Kw] matrices of the four convs it replaces.
+struct CspP {
+  const void* x; int x_cstride, x_coff;          // input view: 2*hid channels of a (B,H,W,x_cstride) tensor
+  void* out; int out_cstride, out_coff;          // output view: 2*hid channels
+  const void* w12; int kw12; const float* b12;   // cv1 | cv2: [2*hid][kw12]
+  const void* wr; int kwr; const float* br;      // m.0.cv1 (RepConvN): [hid][kwr], k = tap*hid + c
+  const void* wb; int kwb; const float* bb;      // m.0.cv2: [hid][kwb]
+  const void* w3; int kw3; const float* b3;      // cv3: [2*hid][kw3], k = [m-branch | cv2]
+  int B, H, W, hid;
+  int tx, tiles; float inv_tiles, inv_tx;        // filled by the launcher: 8x16 tiles per row / per image
+  int dbg;                                       // development: 1..3 = stop after that stage and write its intermediate to `out`
+  int stream;                                    // 1: take the weight-streaming one-tile-per-block variant even where the weights fit in LDS
+};
+bool csp_fused_supported(int dt, int hid);
+void launch_csp_fused(int dt, const CspP& p, hipStream_t stream);
+
 // ---- pooling (pool.hip) ------------------------------------------------------------------------
 struct PoolP {
   const void* in; int in_cstride, in_coff;

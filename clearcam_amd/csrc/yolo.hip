@@ -45,8 +45,8 @@ struct View { int buf; int coff; int C; };
 struct In { View v; int shift; };
 
 struct Op {
-  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms, 4 fuse, 5 letterbox + first conv (launched before the graph: it reads the caller's frames)
-  ConvP conv; PoolP pool; DecodeP dec; NmsP nms; FuseP fuse; StemP stem;
+  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms, 4 fuse, 5 letterbox + first conv (launched before the graph: it reads the caller's frames), 6 fused RepNCSP
+  ConvP conv; PoolP pool; DecodeP dec; NmsP nms; FuseP fuse; StemP stem; CspP csp;
   double alg_macs = 0;   // algorithmic multiply-accumulates of this launch (no padding / densification)
 };
 
@@ -248,11 +248,54 @@ struct Builder {
   int dimH(const In& in) { return P->bufs[in.v.buf].H << in.shift; }
   int dimW(const In& in) { return P->bufs[in.v.buf].W << in.shift; }
 
+  // The four launches of a RepNCSP with one bottleneck as one kernel (csp_fused.hip); 16-bit storage.  Default: hidden width 32
+  // (weights resident in LDS, 2x the four launches); CLEARCAM_FUSE_CSP=2 also takes hidden width 64 (weights streamed: measured
+  // slower than the four launches), =0 keeps the layer-at-a-time path everywhere.  Read per plan, so a test can build both in
+  // one process.
+  bool fuse_csp(View in, int hid, int index) const {
+    const char* e = getenv("CLEARCAM_FUSE_CSP");
+    const int level = e ? atoi(e) : 1;
+    if (level == 0 || (level == 1 && hid != 32)) return false;
+    const char* only = getenv("CLEARCAM_CSP_ONLY");                 // development: fuse just this block (csp_debug.py)
+    if (only && atoi(only) != index) return false;
+    return a.rep_n == 1 && csp_fused_supported(Y->dtype, hid) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0;
+  }
+  void csp_fused(const std::string& r, View in, View out, int hid) {
+    Op op{}; op.kind = 6; CspP& q = op.csp;
+    const Buf& ib = P->bufs[in.buf]; const Buf& ob = P->bufs[out.buf];
+    CC_CHECK(ib.H == ob.H && ib.W == ob.W && out.C == 2 * hid, "fused RepNCSP: view mismatch");
+    const std::string m = r + ".m.list.0";
+    const PackedConv &c12 = pconv({r + ".cv1.conv", r + ".cv2.conv"}, {1, 1}), &cr = pconv({m + ".cv1.conv"}, {1}), &cb = pconv({m + ".cv2.conv"}, {1}),
+                     &c3 = pconv({r + ".cv3.conv"}, {1});
+    CC_CHECK(c12.cin == 2 * hid && c12.cout == 2 * hid && cr.cin == hid && cr.cout == hid && cr.k == 3 && cb.cin == hid && cb.cout == hid && cb.k == 3 &&
+             c3.cin == 2 * hid && c3.cout == 2 * hid, "fused RepNCSP: unexpected conv shapes");
+    q.x = (const void*)(intptr_t)in.buf; q.x_cstride = ib.C; q.x_coff = in.coff;
+    q.out = (void*)(intptr_t)out.buf; q.out_cstride = ob.C; q.out_coff = out.coff;
+    q.w12 = c12.w; q.kw12 = c12.kw; q.b12 = c12.bias; q.wr = cr.w; q.kwr = cr.kw; q.br = cr.bias;
+    q.wb = cb.w; q.kwb = cb.kw; q.bb = cb.bias; q.w3 = c3.w; q.kw3 = c3.kw; q.b3 = c3.bias;
+    q.B = P->B; q.H = ib.H; q.W = ib.W; q.hid = hid;
+    { const char* e = getenv("CLEARCAM_CSP_DBG"); q.dbg = e ? atoi(e) : 0; }
+    { const char* e = getenv("CLEARCAM_CSP_STREAM"); q.stream = e ? atoi(e) : 0; }
+    op.alg_macs = (double)P->B * ib.H * ib.W * (c12.macs_px + cr.macs_px + cb.macs_px + c3.macs_px);
+    P->ops.push_back(op);
+  }
+
   // RepNCSP (:92-105) + trailing 3x3 Conv (:112,115): in -> out
+  int n_csp = 0;
   void csp_branch(const std::string& p, View in, View out, int hid) {
     const int H = P->bufs[in.buf].H, W = P->bufs[in.buf].W;
-    const int csp = new_buf(H, W, 2 * hid), t = new_buf(H, W, hid), u = new_buf(H, W, 2 * hid);
     const std::string r = p + ".list.0";
+    const bool tap = getenv("CLEARCAM_TAP_CSP") != nullptr;          // tests: keep the block's tensors readable (costs arena)
+    const std::string tn = "csp" + std::to_string(n_csp);
+    if (fuse_csp(in, hid, n_csp++)) {
+      const int u = new_buf(H, W, 2 * hid);
+      if (tap) P->taps[tn + "_u"] = u;
+      csp_fused(r, in, whole(u), hid);
+      conv({{whole(u), 0}}, pconv({p + ".list.1.conv"}, {1}), out, 1, 1);
+      return;
+    }
+    const int csp = new_buf(H, W, 2 * hid), t = new_buf(H, W, hid), u = new_buf(H, W, 2 * hid);
+    if (tap) { P->taps[tn + "_ab"] = csp; P->taps[tn + "_t"] = t; P->taps[tn + "_u"] = u; }
     conv({{in, 0}}, pconv({r + ".cv1.conv", r + ".cv2.conv"}, {1, 1}), whole(csp), 1, 1);
     const View x1 = slice(whole(csp), 0, hid);
     for (int j = 0; j < a.rep_n; ++j) {
@@ -474,6 +517,7 @@ struct Builder {
       else if (op.kind == 2) { for (int l = 0; l < 3; ++l) touch(op.dec.raw[l], t); }
       else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) touch(op.fuse.in[k], t); touch(op.fuse.out, t); }
       else if (op.kind == 5) touch(op.stem.out, -1);           // runs before the graph, whatever its position in the list
+      else if (op.kind == 6) { touch(op.csp.x, t); touch(op.csp.out, t); }
     }
     first[P->in_buf] = -1;                                     // written by the letterbox kernel before the first op
     for (auto& kv : P->taps) last[kv.second] = nops + 1;       // cc_yolo_get_tensor reads these after the run
@@ -522,6 +566,7 @@ struct Builder {
       else if (op.kind == 2) { for (int l = 0; l < 3; ++l) op.dec.raw[l] = (const float*)ptr(op.dec.raw[l]); op.dec.det = P->det; }
       else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) op.fuse.in[k] = ptr(op.fuse.in[k]); op.fuse.out = ptr(op.fuse.out); }
       else if (op.kind == 5) op.stem.out = ptr(op.stem.out);
+      else if (op.kind == 6) { op.csp.x = ptr(op.csp.x); op.csp.out = ptr(op.csp.out); }
       else { op.nms.det = P->det; op.nms.out = P->out_dev; }
     }
   }
@@ -562,6 +607,7 @@ static void run_ops(cc_yolo* Y, Plan* P, hipStream_t s) {
     else if (op.kind == 2) launch_decode(op.dec, s);
     else if (op.kind == 4) launch_fuse(Y->dtype, op.fuse, s);
     else if (op.kind == 5) continue;                          // launched by run_stems, outside the graph
+    else if (op.kind == 6) launch_csp_fused(Y->dtype, op.csp, s);
     else launch_topk_nms(op.nms, s);
   }
 }
@@ -697,6 +743,20 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
   if (P->fused_stem) run_stems(h, P, fdev, s);
   else launch_preprocess(h->dtype, pp, s);
   P->last_frames = fdev;
+  if (getenv("CLEARCAM_EAGER_DEBUG")) {                      // development: launch by launch with a sync and a trace line after each
+    int i = 0;
+    for (const Op& op : P->ops) {
+      if (op.kind == 0) launch_conv(h->dtype, op.conv, s);
+      else if (op.kind == 1) launch_pool(h->dtype, op.pool, s);
+      else if (op.kind == 2) launch_decode(op.dec, s);
+      else if (op.kind == 4) launch_fuse(h->dtype, op.fuse, s);
+      else if (op.kind == 6) launch_csp_fused(h->dtype, op.csp, s);
+      else if (op.kind == 3) launch_topk_nms(op.nms, s);
+      const hipError_t e = hipStreamSynchronize(s);
+      fprintf(stderr, "[clearcam] op %d kind %d: %s\n", i, op.kind, hipGetErrorString(e)); fflush(stderr);
+      ++i;
+    }
+  } else
   CC_HIP(hipGraphLaunch(P->exec, s));
   CC_HIP(hipEventRecord(h->ev1, s));
   const size_t ob = (size_t)B * CC_MAX_DET * 6 * 4;
@@ -784,6 +844,7 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
       else if (op.kind == 2) launch_decode(op.dec, s);
       else if (op.kind == 4) launch_fuse(h->dtype, op.fuse, s);
       else if (op.kind == 5) { StemP q = op.stem; q.pre.frames = P->last_frames; launch_stem_fused(h->dtype, q, s); }
+      else if (op.kind == 6) launch_csp_fused(h->dtype, op.csp, s);
       else launch_topk_nms(op.nms, s);
       CC_HIP(hipEventRecord(ev[2 * i + 1], s));
     }
@@ -791,10 +852,10 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
     for (size_t i = 0; i < n; ++i) {
       float t = 0; CC_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
       const int kd = P->ops[i].kind;
-      acc[kd == 4 ? 1 : (kd == 5 ? 4 : kd)] += t;               // CBFuse counts with the pools; the fused letterbox + stem has its own slot
+      acc[kd == 4 ? 1 : (kd == 5 ? 4 : (kd == 6 ? 0 : kd))] += t;   // CBFuse counts with the pools; the fused letterbox + stem has its own slot; a fused RepNCSP is conv work
     }
   }
-  for (const Op& op : P->ops) if (op.kind == 0) { macs += op.alg_macs; ++nconv; }
+  for (const Op& op : P->ops) if (op.kind == 0 || op.kind == 6) { macs += op.alg_macs; ++nconv; }
   if (const char* path = getenv("CLEARCAM_PROFILE_CSV")) {   // per-launch table for tuning
     FILE* f = fopen(path, "w");
     if (f) {
@@ -819,6 +880,11 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
           const double bytes = (double)q.pre.B * q.pre.H * q.pre.W * 3 * (q.pre.frame_f32 ? 4 : 1) + M * q.Cout * es;
           fprintf(f, "%zu,stem_fused,%.4f,%.0f,%d,27,3,2,3,%.4f,%.1f,%.4f,%.0f\n", i, t, M, q.Cout, op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12,
                   bytes / 1e9, bytes / (t * 1e-3) / 1e9);
+        } else if (op.kind == 6) {
+          const CspP& q = op.csp; const double M = (double)q.B * q.H * q.W, es = dtype_size(h->dtype);
+          const double bytes = M * 4 * q.hid * es + (double)(8 + 18) * q.hid * q.hid * es;     // x in, out out, the four weight matrices
+          fprintf(f, "%zu,csp_fused,%.4f,%.0f,%d,%d,3,1,%d,%.4f,%.1f,%.4f,%.0f\n", i, t, M, 2 * q.hid, (8 + 18) * q.hid, 2 * q.hid, op.alg_macs / 1e9,
+                  2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9);
         } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : "topk_nms"), t);
       }
       fclose(f);

@@ -75,6 +75,10 @@ SPECIAL_CASES = [
     ("ws_64_32", 2, 64, 9, 17, 32, 4),
     ("ws_64_48", 1, 64, 16, 16, 48, 4),                  # Cout not a tile multiple
     ("generic_forced", 1, 64, 16, 16, 64, 2),
+    ("small_256_256", 1, 256, 20, 20, 256, 9),           # few-tile configuration: 32-wide channel tiles, four LDS stages, 36 K steps
+    ("small_128_320", 1, 128, 40, 40, 320, 9),           # ten channel tiles, ragged last pixel tile (M = 1600)
+    ("small_64_80", 2, 64, 13, 21, 80, 9),               # Cout not a tile multiple, M = 546
+    ("small_forced_big", 4, 64, 80, 80, 576, 9),         # too many blocks for 32-wide tiles: the 64-wide / three-stage form
     ("wave_64_64", 5, 64, 24, 48, 64, 8),                # more sub-tiles than waves: the persistent loop, patch prefetch under the epilogue
     ("wave_64_64_ragged", 2, 64, 13, 21, 64, 8),         # odd height (half-used 2-row sub-tiles), ragged width
     ("wave_32_32", 3, 32, 16, 32, 32, 8),                # sixteen waves per block, 64-byte rows
@@ -117,6 +121,23 @@ def test_specialised_3x3_kernels_match_torch(case, dtype):
     assert err <= TOL[dtype], err
     generic = conv_hip(x, w, b, 1, 1, 1, dtype, force_direct=2)      # same products, same f32 accumulation order per k-slab? no: only close
     assert float((got - generic).abs().max() / ref.abs().max()) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", [("1x1_k256", 1, 256, 40, 40, 256, 1, 1), ("1x1_k1024", 1, 1024, 20, 20, 512, 1, 1), ("3x3_s2", 1, 128, 39, 39, 128, 3, 2),
+                                  ("1x1_k64", 1, 64, 80, 80, 64, 1, 1), ("3x3_k288", 1, 32, 48, 48, 32, 3, 1)], ids=lambda c: c[0])
+def test_few_tile_configuration_matches_default(case, dtype):
+    """Variant 9 (narrow channel tiles, 3-4 LDS stages, the batch-1 path) against torch and against the default selection: the
+    K order of the accumulation is the same in every MFMA kernel, so the two agree bit for bit."""
+    _, B, Cin, H, W_, Cout, k, stride = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b, stride=stride, padding=k // 2))
+    got = conv_hip(x, w, b, stride, 1, 1, dtype, force_direct=9)
+    assert float((got - ref).abs().max() / ref.abs().max()) <= TOL[dtype]
+    assert torch.equal(got, conv_hip(x, w, b, stride, 1, 1, dtype, force_direct=2))
 
 
 def test_specialised_kernels_refuse_ineligible_shapes():
@@ -453,3 +474,49 @@ def test_fused_letterbox_stem_equals_unfused(tmp_path, size, res, dtype, H, W, f
     assert np.abs(b["stem"] - ref).max() <= 2 * ulp * max(1.0, float(np.abs(ref).max()))
     n0, n1, nm, _, _ = yo.match_detections(a["det"][0], b["det"][0], 0.5)
     assert nm >= 0.7 * max(n0, n1, 1) - 1                                      # end to end the two modes stay the same detector
+
+
+_CSP_SCRIPT = r"""
+import sys, numpy as np
+from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict
+from clearcam_amd.yolov9 import YOLOv9
+size, res, dtype, H, W, B, out = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+frames = np.random.default_rng(5).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+sd = conditioned_yolov9_state_dict(size, 1234) if size == "c" else synthetic_yolov9_state_dict(size, 1234)
+m = YOLOv9(size, res, state_dict=sd, dtype=dtype, device=0)
+d = {"det": m.detect_batch(frames)}
+for k in range(16):
+    try: d[f"csp{k}_u"] = m.get_tensor(f"csp{k}_u")
+    except Exception: pass
+for n in ("p3", "p4", "p5"): d[n] = m.get_tensor(n)
+d["launches"] = np.array(m.profile(iters=1)["conv_launches"])
+np.savez(out, **d)
+"""
+
+
+@pytest.mark.parametrize("size,res,dtype,H,W,B,level,fused", [
+    ("c", 640, "bf16", 640, 640, 3, "1", 2),      # the bench plan's shapes: hidden width 32 at 160x160 (weights resident, persistent blocks)
+    ("c", 640, "f16", 640, 640, 1, "2", 6),       # + hidden width 64 at 80x80 (weights streamed); a single frame: fewer tiles than CUs
+    ("c", 608, "bf16", 608, 608, 2, "2", 6),      # 152 x 152 and 76 x 76 maps: ragged 8 x 16 tiles on both axes
+    ("c", 640, "bf16", 270, 480, 2, "2", 6),      # letterboxed 384 x 640: non-square maps
+    ("m", 320, "f16", 320, 320, 2, "1", 2),       # YOLOv9-m: one bottleneck per RepNCSP, hidden width 32 at 80x80
+])
+def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fused):
+    """csp_fused_kernel (cv1|cv2, RepConvN 3x3, 3x3 + shortcut, cv3 of a RepNCSP in one launch, intermediates in LDS) against the
+    four launches it replaces: every intermediate is rounded where the layer-at-a-time path stores it and every accumulation runs
+    in the same K order, so block outputs, P3-P5 and the detections are IDENTICAL, bit for bit."""
+    import subprocess
+    import sys
+    outs = []
+    for lv in ("0", level):
+        path = str(tmp_path / f"csp{lv}.npz")
+        env = dict(os.environ, CLEARCAM_FUSE_CSP=lv, CLEARCAM_TAP_CSP="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", _CSP_SCRIPT, size, str(res), dtype, str(H), str(W), str(B), path], check=True, env=env)
+        outs.append(np.load(path))
+    a, b = outs
+    assert int(a["launches"]) - int(b["launches"]) == 3 * fused                # four launches became one, `fused` times
+    names = [n for n in a.files if n.startswith("csp")]
+    assert len(names) >= fused
+    for n in names + ["p3", "p4", "p5", "det"]:
+        assert np.array_equal(a[n], b[n]), n
+    assert np.abs(a["p3"]).max() > 0.05 and np.isfinite(a["p3"]).all()
