@@ -209,11 +209,10 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
 
   // ---- prologue ----------------------------------------------------------------------------------------------------------------
   int x_off = 0;                                                   // byte offset of the current tile's patch (T and U alias it)
-  if (tid < G::BIAS_BYTES / 4 && !(p.dbg & 1024)) {                // the four bias vectors -> LDS (published by the first barrier)
+  if (tid < G::BIAS_BYTES / 4) {                                                  // the four bias vectors -> LDS (published by the first barrier)
     const float* src = tid < C2 ? p.b12 + tid : tid < C2 + HID ? p.br + (tid - C2) : tid < C2 + 2 * HID ? p.bb + (tid - C2 - HID) : p.b3 + (tid - C2 - 2 * HID);
     reinterpret_cast<float*>(ldsb + OFF_BIAS)[tid] = *src;
   }
-  if (p.dbg & 4096) return;
   if (tile < tile_end) issue_x(tile, 0);
   if constexpr (RES) {
     issue_w(p.w12, p.kw12, IC<C2>{}, 0, IC<NSLAB>{}, G::R_OFF_W12);
@@ -225,7 +224,6 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
   }
 
   wait_vmcnt<0>();                                                 // first patch, resident weights / first chunk
-  if (p.dbg & 2048) return;
   for (; tile < tile_end; tile += tile_step) {
     {
       b = fdiv(tile, p.tiles, p.inv_tiles);
@@ -236,7 +234,6 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
     // every wave is done with the previous tile (its staging copy-out out of A, its reads of B and U) and the other patch buffer is
     // free.  This tile's patch has landed: the first one was waited for above, later ones at the opening of the previous tile's
     // stage 4 - so that the previous tile's output stores are NOT waited for here and drain under this tile.
-    if (p.dbg & 256) wait_vmcnt<0>();
     __syncthreads();
     if constexpr (RES) { if (tile + tile_step < tile_end) issue_x(tile + tile_step, G::X_BYTES - x_off); }
     else issue_chunk(IC<1>{});

@@ -254,7 +254,7 @@ struct Builder {
   // one process.
   bool fuse_csp(View in, int hid, int index) const {
     const char* e = getenv("CLEARCAM_FUSE_CSP");
-    const int level = e ? atoi(e) : 1;
+    const int level = e ? atoi(e) : 2;
     if (level == 0 || (level == 1 && hid != 32)) return false;
     const char* only = getenv("CLEARCAM_CSP_ONLY");                 // development: fuse just this block (csp_debug.py)
     if (only && atoi(only) != index) return false;

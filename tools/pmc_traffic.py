@@ -47,7 +47,7 @@ def main():
     fetch, fcalls = run_pass("FETCH_SIZE", base + "_f")
     write, wcalls = run_pass("WRITE_SIZE", base + "_w")
     replays = PASSES + 1
-    is_conv = lambda k: k.startswith("conv")                                  # noqa: E731  every conv kernel family of conv_mfma.hip / conv_direct.hip / fused kernels
+    is_conv = lambda k: k.startswith("conv") or k.startswith("csp_fused")                                  # noqa: E731  every conv kernel family of conv_mfma.hip / conv_direct.hip / fused kernels
     lines, conv_r, conv_w, pool_r, pool_w = [], 0.0, 0.0, 0.0, 0.0
     for k in sorted(set(fetch) | set(write)):
         r_b, w_b = 2.0 * fetch.get(k, 0.0) * 1024 / replays, write.get(k, 0.0) * 1024 / replays
