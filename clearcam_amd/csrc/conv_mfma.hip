@@ -787,6 +787,8 @@ template <class T> static void launch_ws_t(const ConvP& p, hipStream_t stream) {
 }
 
 static bool halo_applicable(const ConvP& p);
+static bool ws_legal(const ConvP& p);
+template <class T> static void launch_ws_t(const ConvP& p, hipStream_t stream);
 
 // Few-tile layers (a single frame, or the 20x20 maps of a batch): the grid does not fill the chip, one block per CU at best, and a
 // K step is then paced by the round trip of the DMA issued one step earlier (~0.6 us per step measured at batch 1: a 36-step 3x3
@@ -802,7 +804,8 @@ template <class T> static bool launch_small(const ConvP& p, int M, hipStream_t s
   if (b32 <= 512) bn = 32; else if (b64 <= 512) bn = 64;
   if (force && !bn) bn = 64;
   if (!bn) return false;
-  const bool deep = bn == 32 && b32 <= 256;            // at most one block per CU anyway: six stages (120 KB), prefetch distance five
+  bool deep = bn == 32 && b32 <= 256;                  // at most one block per CU anyway: six stages (120 KB), prefetch distance five
+  if (p.variant >= 91 && p.variant <= 93) { bn = p.variant == 93 ? 64 : 32; deep = p.variant == 92; }   // tuning sweeps: 91 32/4, 92 32/6, 93 64/3
   ConvAux a{};
   a.nt = (p.Cout + bn - 1) / bn;
   a.inv_hw = 1.0f / (float)(p.Ho * p.Wo); a.inv_wo = 1.0f / (float)p.Wo;
@@ -820,7 +823,10 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
     // (layers the halo-resident kernel takes at any batch size keep it: its K order is (channel slab, tap), every other kernel's
     //  (tap, channel), and a frame's result must not depend on the batch it arrives in - test_batch_invariance_and_determinism)
-    if (((p.variant == 0 && !halo_applicable(p)) || p.variant == 9) && launch_small<T>(p, M, stream, p.variant == 9)) return;
+    //  narrow 3x3 layers on a few tiles go to the weights-stationary kernel instead: 6.5-7.3 us against 8.5-10.5 at batch 1 (same K order))
+    const bool few_narrow = p.variant == 0 && ws_legal(p) && (long)((M + 127) / 128) * ((p.Cout + 31) / 32) <= 512;
+    if (few_narrow) { launch_ws_t<T>(p, stream); CC_HIP(hipGetLastError()); return; }
+    if (((p.variant == 0 && !halo_applicable(p)) || p.variant == 9 || (p.variant >= 91 && p.variant <= 93)) && launch_small<T>(p, M, stream, p.variant >= 9)) return;
     {   // narrow 3x3 layers: one autonomous wave per 2x16-pixel sub-tile over LDS-resident weights (conv_wave.hip).
         // CLEARCAM_WAVE=0 falls back to the cooperative kernels below; tests force it with variant 8.
       static int wave_on = -1;

@@ -897,6 +897,35 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
   CC_API_END
 }
 
+int cc_yolo_profile_conv_graph(cc_yolo* h, int iters, float* ms_per_step) {
+  CC_API_BEGIN
+  CC_CHECK(h && ms_per_step && h->last && iters > 0, "bad argument / no detect call yet");
+  Plan* P = h->last;
+  CC_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  CC_HIP(hipStreamSynchronize(s));
+  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  CC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  try {
+    for (const Op& op : P->ops) {
+      if (op.kind == 0) launch_conv(h->dtype, op.conv, s);
+      else if (op.kind == 6) launch_csp_fused(h->dtype, op.csp, s);
+    }
+  } catch (...) { hipStreamEndCapture(s, &graph); if (graph) hipGraphDestroy(graph); throw; }
+  CC_HIP(hipStreamEndCapture(s, &graph));
+  CC_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  CC_HIP(hipGraphDestroy(graph));
+  for (int i = 0; i < 2; ++i) CC_HIP(hipGraphLaunch(exec, s));          // warm-up
+  CC_HIP(hipEventRecord(h->ev0, s));
+  for (int i = 0; i < iters; ++i) CC_HIP(hipGraphLaunch(exec, s));
+  CC_HIP(hipEventRecord(h->ev1, s));
+  CC_HIP(hipEventSynchronize(h->ev1));
+  float t = 0; CC_HIP(hipEventElapsedTime(&t, h->ev0, h->ev1));
+  CC_HIP(hipGraphExecDestroy(exec));
+  *ms_per_step = t / iters;
+  CC_API_END
+}
+
 void cc_yolo_destroy(cc_yolo* h) {
   if (!h) return;
   hipSetDevice(h->device);

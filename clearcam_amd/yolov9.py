@@ -111,6 +111,12 @@ class YOLOv9:
         return {"conv_ms": ms[0], "pool_ms": ms[1], "decode_ms": ms[2], "nms_ms": ms[3], "stem_ms": ms[4],
                 "alg_macs_per_step": macs.value, "conv_launches": n.value}
 
+    def profile_conv_graph(self, iters: int = 10) -> float:
+        """ms per step of the plan's conv / GEMM launches replayed back to back in a hipGraph of their own (one event pair)."""
+        ms = C.c_float()
+        _lib.check(_lib.lib().cc_yolo_profile_conv_graph(self._h, iters, C.byref(ms)))
+        return ms.value
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().cc_yolo_destroy(self._h)

@@ -1,0 +1,30 @@
+"""dev: every distinct conv shape of a per-launch table (gpurun_out/ab_*.csv) under every forced kernel variant (cc_conv_bench):
+which kernel the selection rules SHOULD pick.   python tools/dev/variant_sweep.py gpurun_out/ab_fused2_b64.csv 64"""
+import csv, ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from clearcam_amd import _lib
+L = _lib.lib()
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["kind"] == "conv"]
+B = int(sys.argv[2])
+shapes = {}
+for r in rows:
+    M, Cin, Cout, ks, st = int(float(r["M"])), int(r["Cin"]), int(r["Cout"]), int(r["ks"]), int(r["stride"])
+    key = (M, Cin, Cout, ks, st)
+    shapes.setdefault(key, [0, 0.0]); shapes[key][0] += 1; shapes[key][1] += float(r["ms"])
+names = {0: "auto", 2: "generic", 3: "halo", 4: "ws", 5: "big256", 6: "big128", 7: "phase", 8: "wave", 91: "s32/4", 92: "s32/6", 93: "s64/3"}
+print("shape (M Cin Cout k s) x n, in-plan us | " + " ".join(f"{n:>7}" for n in names.values()))
+tot_auto = tot_best = 0.0
+for (M, Cin, Cout, ks, st), (n, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+    Ho = int(round((M / B) ** 0.5)); H = Ho * st
+    if Ho * Ho * B != M or Cin % 8 or Cout % 8:
+        continue
+    res = {}
+    for v in names:
+        t = C.c_float()
+        rc = L.cc_conv_bench(2, B, H, H, Cin, Cout, ks, st, 1, v, 20, C.byref(t))
+        res[v] = t.value * 1e3 if rc == 0 else float("nan")
+    best = min((x, v) for v, x in res.items() if x == x)
+    tot_auto += n * res[0]; tot_best += n * best[0]
+    print(f"{M:8d} {Cin:5d} {Cout:4d} {ks} {st} x{n:2d} {ms / n * 1e3:7.1f} | " + " ".join(f"{res[v]:7.1f}" for v in names) + f"  best {names[best[1]]}", flush=True)
+print(f"sum over launches: auto {tot_auto / 1e3:.3f} ms, best-per-shape {tot_best / 1e3:.3f} ms")
