@@ -17,6 +17,23 @@ CLEARCAM_PROFILE_CSV=$root/gpurun_out/${tag}_yolo_per_launch_b1.csv python tools
 f=$(find /tmp/kt_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${tag}_yolo_kernel_stats.csv
 python tools/prof_summary.py /tmp/kt_$tag > gpurun_out/${tag}_yolo_bf16_b64.txt 2>/dev/null
+python - "$tag" <<'PY'
+import csv, json, os, sys
+from bench import kernel_source_digest
+tag = sys.argv[1]
+rows = list(csv.DictReader(open(f"gpurun_out/{tag}_yolo_kernel_stats.csv")))
+fam = lambda n: "conv" if ("conv" in n or "csp_fused" in n) else "stem" if "stem_fused" in n else "pool" if "pool" in n else "other"   # noqa: E731
+tot = {}
+for r in rows:
+    tot[fam(r["Name"])] = tot.get(fam(r["Name"]), 0.0) + float(r["TotalDurationNs"]) / 1e6
+rec = {"kernel_source_digest": kernel_source_digest(), "tag": tag, "replays": 10,
+       "command": "rocprofv3 --kernel-trace --stats -- python tools/dev/plan_passes.py 9   (10 replays of the bench plan, YOLOv9-C bf16 B=64 640x640)",
+       "conv_ms_per_step": tot.get("conv", 0.0) / 10, "pool_ms_per_step": tot.get("pool", 0.0) / 10, "stem_ms_per_step": tot.get("stem", 0.0) / 10,
+       "all_kernels_ms_per_step": sum(tot.values()) / 10}
+json.dump(rec, open("gpurun_out/kernel_trace.json", "w"), indent=1)
+json.dump(rec, open("profiles/kernel_trace.json", "w"), indent=1)
+print(json.dumps(rec))
+PY
 (cd /tmp && python $root/tools/pmc_traffic.py $tag > $root/gpurun_out/${tag}_pmc.log 2>&1)
 cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json 2>/dev/null
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
