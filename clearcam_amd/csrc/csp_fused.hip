@@ -68,7 +68,7 @@ template <class T, int HID, bool RES>
 __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
   using G = CspGeom<HID>;
   constexpr int C2 = G::C2, NSLAB = G::NSLAB, PW = G::PW, PR = G::PR, QW = G::QW, QR = G::QR, CPA = G::CPA, PA = G::PA;
-  constexpr int NJ1 = C2 / 16, NJ2 = HID / 32, NJ4 = HID / 16, SPC = G::SPC, NS3 = G::NS3, NC3 = G::NC3;
+  constexpr int NJ1 = C2 / 16, NJ2 = HID / 32, SPC = G::SPC, NS3 = G::NS3, NC3 = G::NC3;
   constexpr int OFF_A = RES ? G::R_OFF_A : G::S_OFF_A, OFF_B = RES ? G::R_OFF_B : G::S_OFF_B, OFF_BIAS = RES ? G::R_OFF_BIAS : G::S_OFF_BIAS;
   constexpr int BI_12 = OFF_BIAS, BI_R = BI_12 + C2 * 4, BI_B = BI_R + HID * 4, BI_3 = BI_B + HID * 4;
   static_assert(sizeof(T) == 2 && (HID == 32 || HID == 64), "16-bit storage, hidden width 32 or 64");
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
     constexpr int ST = decltype(st_c)::value, SL = decltype(sl_c)::value;
     if constexpr (RES) {
       if constexpr (SL == 0 && ST == 3) wait_vmcnt<0>();           // the next tile's patch (issued a whole tile ago) has landed
-      if constexpr (SL == 0 && ST > 0) __syncthreads();
+      if constexpr (SL == 0 && (ST == 1 || ST == 2)) __syncthreads();   // stage 4 reads what its own wave wrote (u) and b from stage 1
       return ST == 0 ? G::R_OFF_W12 + SL * G::SLAB_BIG : ST == 1 ? G::R_OFF_WR + SL * G::SLAB_SMALL : ST == 2 ? G::R_OFF_WB + SL * G::SLAB_SMALL : G::R_OFF_W3 + SL * G::SLAB_BIG;
     } else {
       constexpr bool big = ST == 0 || ST == 3;
@@ -187,20 +187,20 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
   };
   // 3x3 over an LDS-resident map: pixel fragment i reads 16 bytes at fp[i] + (r * SRCW + s) * PA (+ 64 for the second K half at
   // HID 64): one base pointer per fragment, every tap a compile-time offset.  K slab J of the stage's weights at woff.
-  auto conv3_slab = [&](auto j_c, int woff, auto npx_c, auto srcw_c, const auto& fp, auto& acc) {
-    constexpr int J = decltype(j_c)::value, NPX = decltype(npx_c)::value, SRCW = decltype(srcw_c)::value;
+  auto conv3_slab = [&](auto j_c, int woff, auto npx_c, auto srcw_c, auto nj_c, int ch0, const auto& fp, auto& acc) {
+    constexpr int J = decltype(j_c)::value, NPX = decltype(npx_c)::value, SRCW = decltype(srcw_c)::value, NJ = decltype(nj_c)::value;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       const int tap = HID == 64 ? J : 2 * J + kh;                  // a 64-wide K slab is one tap (HID 64) or two (HID 32)
       if (tap < 9) {
         const int r = tap / 3, s = tap - r * 3;
-        uint4 xf[NPX], wf[NJ2];
+        uint4 xf[NPX], wf[NJ];
 #pragma unroll
         for (int i = 0; i < NPX; ++i) xf[i] = *reinterpret_cast<const uint4*>(fp[i] + (r * SRCW + s) * PA + (HID == 64 ? kh * 64 : 0));
 #pragma unroll
-        for (int jj = 0; jj < NJ2; ++jj) { const int n = (chh * NJ2 + jj) * 16 + fr; wf[jj] = *reinterpret_cast<const uint4*>(ldsb + woff + n * 128 + (((kh * 4 + fg) ^ swz<8>(n)) << 4)); }
+        for (int jj = 0; jj < NJ; ++jj) { const int n = (ch0 + jj) * 16 + fr; wf[jj] = *reinterpret_cast<const uint4*>(ldsb + woff + n * 128 + (((kh * 4 + fg) ^ swz<8>(n)) << 4)); }
 #pragma unroll
-        for (int jj = 0; jj < NJ2; ++jj)
+        for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
           for (int i = 0; i < NPX; ++i) Mma<T>::run(wf[jj], xf[i], acc[jj][i]);
       }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
       }
       static_for<NS3>([&](auto j_c) {
         const int woff = open_slab(IC<1>{}, j_c);
-        conv3_slab(j_c, woff, IC<3>{}, IC<PW>{}, fp, acc);
+        conv3_slab(j_c, woff, IC<3>{}, IC<PW>{}, IC<NJ2>{}, chh * NJ2, fp, acc);
       });
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -321,34 +321,31 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
       if constexpr (RES) { x_off = G::X_BYTES - x_off; continue; } else return;
     }
 
-    // ---- stage 3: u = a + SiLU(Wb * t + bb) on the 8 x 16 inner pixels; wave = (output rows 2pg, 2pg+1) x (channel half) ----------
+    // ---- stage 3: u = a + SiLU(Wb * t + bb) on the 8 x 16 inner pixels.  From here on a wave OWNS output row `wave` (one 16-pixel
+    // fragment) with all its channels: stage 4 then reads only what its own wave wrote (u) or what stage 1 wrote two barriers ago
+    // (b), and the store epilogue stages through the wave's own rows - no barrier between stage 3 and the end of the tile.
+    constexpr int NJ3 = HID / 16;
+    const int qrow = 16 * wave + fr;                               // this lane's inner pixel
     {
-      f32x4 acc[NJ2][2];
-      const char* fp[2];
+      f32x4 acc[NJ3][1];
+      const char* fp[1] = {ldsb + off_t + (wave * QW + fr) * PA + fg * 16};
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fp[i] = ldsb + off_t + ((2 * pg + i) * QW + fr) * PA + fg * 16;
-#pragma unroll
-        for (int jj = 0; jj < NJ2; ++jj) acc[jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int jj = 0; jj < NJ3; ++jj) acc[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       static_for<NS3>([&](auto j_c) {
         const int woff = open_slab(IC<2>{}, j_c);
-        conv3_slab(j_c, woff, IC<2>{}, IC<QW>{}, fp, acc);
+        conv3_slab(j_c, woff, IC<1>{}, IC<QW>{}, IC<NJ3>{}, 0, fp, acc);
       });
+      const int arow = (wave + 2) * PW + fr + 2;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int oy = 2 * pg + i, q = 16 * oy + fr, arow = (oy + 2) * PW + fr + 2;
-#pragma unroll
-        for (int jj = 0; jj < NJ2; ++jj) {
-          const int n = (chh * NJ2 + jj) * 16 + 4 * fg;
-          const float4 b4 = *reinterpret_cast<const float4*>(ldsb + BI_B + n * 4);
-          const f32x4 av = acc[jj][i];
-          const uint2 ru = *reinterpret_cast<const uint2*>(ldsb + elem_off(OFF_A, arow, n));
-          const T* rt = reinterpret_cast<const T*>(&ru);
-          *reinterpret_cast<uint2*>(ldsb + elem_off(off_u, q, n)) =
-              make_uint2(pack2<T>(to_f32<T>(rt[0]) + activate<T, 1>(av[0] + b4.x), to_f32<T>(rt[1]) + activate<T, 1>(av[1] + b4.y)),
-                         pack2<T>(to_f32<T>(rt[2]) + activate<T, 1>(av[2] + b4.z), to_f32<T>(rt[3]) + activate<T, 1>(av[3] + b4.w)));
-        }
+      for (int jj = 0; jj < NJ3; ++jj) {
+        const int n = 16 * jj + 4 * fg;
+        const float4 b4 = *reinterpret_cast<const float4*>(ldsb + BI_B + n * 4);
+        const f32x4 av = acc[jj][0];
+        const uint2 ru = *reinterpret_cast<const uint2*>(ldsb + elem_off(OFF_A, arow, n));
+        const T* rt = reinterpret_cast<const T*>(&ru);
+        *reinterpret_cast<uint2*>(ldsb + elem_off(off_u, qrow, n)) =
+            make_uint2(pack2<T>(to_f32<T>(rt[0]) + activate<T, 1>(av[0] + b4.x), to_f32<T>(rt[1]) + activate<T, 1>(av[1] + b4.y)),
+                       pack2<T>(to_f32<T>(rt[2]) + activate<T, 1>(av[2] + b4.z), to_f32<T>(rt[3]) + activate<T, 1>(av[3] + b4.w)));
       }
     }
     if (p.dbg == 3) {
@@ -358,10 +355,10 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
       if constexpr (RES) { x_off = G::X_BYTES - x_off; continue; } else return;
     }
 
-    // ---- stage 4: out = SiLU(W3 [u | b] + b3); wave = (pixel fragments 2pg, 2pg+1) x (channels chh*HID .. +HID) -------------------
-    f32x4 acc4[NJ4][2];
+    // ---- stage 4: out = SiLU(W3 [u | b] + b3) for the wave's 16 pixels, all 2*HID channels ----------------------------------------
+    f32x4 acc4[NJ1][1];
 #pragma unroll
-    for (int jj = 0; jj < NJ4; ++jj) { acc4[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc4[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int jj = 0; jj < NJ1; ++jj) acc4[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     static_for<NSLAB>([&](auto s_c) {
       constexpr int S = decltype(s_c)::value;
       const int woff = open_slab(IC<3>{}, s_c);
@@ -369,37 +366,31 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
       for (int kh = 0; kh < 2; ++kh) {
         const int region = (HID == 64 ? S : kh) == 0 ? off_u : OFF_B;          // K order of cv3: the m-branch channels, then cv2's
         const int pc = HID == 64 ? kh * 4 + fg : fg;
-        uint4 xf[2], wf[NJ4];
+        const uint4 xf = *reinterpret_cast<const uint4*>(ldsb + region + qrow * PA + pc * 16);
+        uint4 wf[NJ1];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { const int q = 16 * (2 * pg + i) + fr; xf[i] = *reinterpret_cast<const uint4*>(ldsb + region + q * PA + pc * 16); }
+        for (int jj = 0; jj < NJ1; ++jj) { const int n = 16 * jj + fr; wf[jj] = *reinterpret_cast<const uint4*>(ldsb + woff + n * 128 + (((kh * 4 + fg) ^ swz<8>(n)) << 4)); }
 #pragma unroll
-        for (int jj = 0; jj < NJ4; ++jj) { const int n = chh * HID + 16 * jj + fr; wf[jj] = *reinterpret_cast<const uint4*>(ldsb + woff + n * 128 + (((kh * 4 + fg) ^ swz<8>(n)) << 4)); }
-#pragma unroll
-        for (int jj = 0; jj < NJ4; ++jj)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) Mma<T>::run(wf[jj], xf[i], acc4[jj][i]);
+        for (int jj = 0; jj < NJ1; ++jj) Mma<T>::run(wf[jj], xf, acc4[jj][0]);
       }
     });
-    // bias + SiLU, then through A's bytes (free since the barrier that opened stage 4: its last reader was stage 3's shortcut) so
-    // that every pixel's 2*HID channels leave as 16-byte-per-lane, line-contiguous stores.  Padded rows, no swizzle.
+    // bias + SiLU, then through the wave's OWN u rows (channels 0..HID-1) and b rows (HID..2*HID-1) - both dead for everybody else and,
+    // after the MFMAs above, for this wave - so that every pixel's 2*HID channels leave as 16-byte-per-lane stores.  Same-wave LDS
+    // traffic only: no barrier.
     {
-      constexpr int OROW = C2 * 2 + 16, OCPR = C2 / 8;             // staging row pitch (bytes), 16-byte chunks per pixel
-      static_assert(128 * OROW <= G::A_BYTES, "the output staging tile aliases A");
-      char* tilep = ldsb + OFF_A;
+      constexpr int OCPR = C2 / 8;                                 // 16-byte chunks per pixel
 #pragma unroll
-      for (int jj = 0; jj < NJ4; ++jj) {
-        const int nl = chh * HID + 16 * jj + 4 * fg;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          *reinterpret_cast<uint2*>(tilep + (32 * pg + 16 * i + fr) * OROW + nl * 2) = act4(acc4[jj][i], BI_3 + nl * 4, true);
+      for (int jj = 0; jj < NJ1; ++jj) {
+        const int nl = 16 * jj + 4 * fg;
+        *reinterpret_cast<uint2*>(ldsb + (jj < NJ3 ? elem_off(off_u, qrow, nl) : elem_off(OFF_B, qrow, nl - HID))) = act4(acc4[jj][0], BI_3 + nl * 4, true);
       }
-      __syncthreads();
       T* outp = reinterpret_cast<T*>(p.out) + p.out_coff;
 #pragma unroll
-      for (int it = 0; it < 128 * OCPR / 512; ++it) {
-        const int idx = tid + 512 * it, row = idx / OCPR, ch = idx - row * OCPR;
-        const long m = out_pix(row);
-        if (m >= 0) *reinterpret_cast<uint4*>(outp + m * p.out_cstride + ch * 8) = *reinterpret_cast<const uint4*>(tilep + row * OROW + ch * 16);
+      for (int it = 0; it < 16 * OCPR / 64; ++it) {
+        const int idx = lane + 64 * it, r = idx / OCPR, ch = idx - r * OCPR, q = 16 * wave + r;
+        const long m = out_pix(q);
+        const uint4 v = *reinterpret_cast<const uint4*>(ldsb + (ch < CPA ? off_u + q * PA + ch * 16 : OFF_B + q * PA + (ch - CPA) * 16));
+        if (m >= 0) *reinterpret_cast<uint4*>(outp + m * p.out_cstride + ch * 8) = v;
       }
     }
     if constexpr (RES) x_off = G::X_BYTES - x_off;
