@@ -19,14 +19,19 @@
 // accumulation is the same, so the result is bit-identical to the four launches it replaces
 // (tests/test_gpu_yolo.py::test_fused_csp_equals_unfused).
 //
+// Work split: stage 1 gives wave w patch-pixel fragments w and w+8 (all 2*HID channels); stage 2 gives (pixel group, channel half);
+// from stage 3 on a wave OWNS one 16-pixel output row with all its channels, so stage 4 and the store epilogue (staged through the
+// wave's own u / b rows) need no barrier: three barriers per tile (top, 1->2, 2->3) plus, when weights stream, one per chunk.
+//
 // Two variants of the outer loop:
-//   RES = true  (HID 32: 56 KB of weights): PERSISTENT blocks, one per CU; the four weight matrices are loaded once and stay in
-//               LDS, the input patch is double-buffered (the patch of the next tile streams in under the current tile), so a
-//               tile is four stage barriers and no exposed DMA wait; biases sit in LDS too (no global load in the loop).
-//   RES = false (HID 64: 208 KB of weights cannot stay): one tile per block; weights stream from L2 in chunks of one to three
-//               64-wide K slabs through a two-slot ring, chunk i+1 issued at the barrier that opens chunk i.  Measured slower than
-//               the four launches at HID 64 (every chunk waits a full L2 round trip behind ~0.3 us of MFMA work), so the graph
-//               builder only takes it on request (CLEARCAM_FUSE_CSP=2).
+//   RES = true  (HID 32: 56 KB of weights): PERSISTENT blocks, one per CU; the four weight matrices and the biases are loaded once
+//               and stay in LDS, the input patch is double-buffered (the next tile's patch streams in under the current tile and is
+//               waited for at the opening of stage 4, so output stores are never waited for).  0.296 ms against 0.394 ms for the
+//               four launches at 160x160, batch 64.
+//   RES = false (HID 64: 208 KB of weights cannot stay): one tile per block; weights stream from L2 in chunks of one or two
+//               64-wide K slabs through a two-slot ring, chunk i+1 issued at the barrier that opens chunk i.  0.225 ms against
+//               0.239 ms at 80x80, batch 64; 19 us against ~50 us for a single frame.
+// DESIGN.md section 4 has the timing ablations (the block is bound by its lock-step skeleton and its epilogue VALU, not by MFMA).
 #include <utility>
 #include "conv_tile.h"
 
