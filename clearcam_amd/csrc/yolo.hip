@@ -897,9 +897,9 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
   CC_API_END
 }
 
-int cc_yolo_profile_conv_graph(cc_yolo* h, int iters, float* ms_per_step) {
+int cc_yolo_profile_graph(cc_yolo* h, int iters, int which, float* ms_per_replay) {
   CC_API_BEGIN
-  CC_CHECK(h && ms_per_step && h->last && iters > 0, "bad argument / no detect call yet");
+  CC_CHECK(h && ms_per_replay && h->last && iters > 0 && which >= 0 && which <= 2, "bad argument / no detect call yet");
   Plan* P = h->last;
   CC_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
@@ -908,8 +908,15 @@ int cc_yolo_profile_conv_graph(cc_yolo* h, int iters, float* ms_per_step) {
   CC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   try {
     for (const Op& op : P->ops) {
+      const bool conv = op.kind == 0 || op.kind == 6;
+      if (which == 0 ? !conv : (which == 1 ? conv : false)) continue;
       if (op.kind == 0) launch_conv(h->dtype, op.conv, s);
       else if (op.kind == 6) launch_csp_fused(h->dtype, op.csp, s);
+      else if (op.kind == 1) launch_pool(h->dtype, op.pool, s);
+      else if (op.kind == 2) launch_decode(op.dec, s);
+      else if (op.kind == 4) launch_fuse(h->dtype, op.fuse, s);
+      else if (op.kind == 5) { StemP q = op.stem; q.pre.frames = P->last_frames; launch_stem_fused(h->dtype, q, s); }
+      else launch_topk_nms(op.nms, s);
     }
   } catch (...) { hipStreamEndCapture(s, &graph); if (graph) hipGraphDestroy(graph); throw; }
   CC_HIP(hipStreamEndCapture(s, &graph));
@@ -922,7 +929,7 @@ int cc_yolo_profile_conv_graph(cc_yolo* h, int iters, float* ms_per_step) {
   CC_HIP(hipEventSynchronize(h->ev1));
   float t = 0; CC_HIP(hipEventElapsedTime(&t, h->ev0, h->ev1));
   CC_HIP(hipGraphExecDestroy(exec));
-  *ms_per_step = t / iters;
+  *ms_per_replay = t / iters;
   CC_API_END
 }
 

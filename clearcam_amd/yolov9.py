@@ -111,10 +111,11 @@ class YOLOv9:
         return {"conv_ms": ms[0], "pool_ms": ms[1], "decode_ms": ms[2], "nms_ms": ms[3], "stem_ms": ms[4],
                 "alg_macs_per_step": macs.value, "conv_launches": n.value}
 
-    def profile_conv_graph(self, iters: int = 10) -> float:
-        """ms per step of the plan's conv / GEMM launches replayed back to back in a hipGraph of their own (one event pair)."""
+    def profile_graph(self, which: int, iters: int = 10) -> float:
+        """ms per replay of a subset of the last plan's launches captured into a hipGraph of its own (one event pair around `iters`
+        replays): which = 0 the conv / GEMM launches, 1 every other launch, 2 the whole step."""
         ms = C.c_float()
-        _lib.check(_lib.lib().cc_yolo_profile_conv_graph(self._h, iters, C.byref(ms)))
+        _lib.check(_lib.lib().cc_yolo_profile_graph(self._h, iters, which, C.byref(ms)))
         return ms.value
 
     def close(self):

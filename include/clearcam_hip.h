@@ -62,10 +62,11 @@ int cc_yolo_last_gpu_ms(cc_yolo* h, float* ms);
  * first conv (0 when that fusion is off: f32 mode or CLEARCAM_FUSE_STEM=0; its time is then in the conv slot and in the
  * separate letterbox launch)}; alg_macs_per_step / n_conv_launches cover the launches timed in the conv slot. */
 int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step, int* n_conv_launches);
-/* The conv / GEMM launches of the last plan (the ones cc_yolo_profile counts in its conv slot) captured into a hipGraph of
- * their own and replayed `iters` times between ONE hipEvent pair on the launch stream: their average time per step as they run
- * in production (back to back inside a graph), without the per-launch event records of cc_yolo_profile. */
-int cc_yolo_profile_conv_graph(cc_yolo* h, int iters, float* ms_per_step);
+/* A subset of the last plan's launch list captured into a hipGraph of its own and replayed `iters` times between ONE hipEvent
+ * pair on the launch stream (no per-launch event records): average milliseconds per replay.
+ * which = 0: the conv / GEMM launches (the ones cc_yolo_profile counts in its conv slot), 1: every other launch (pooling, decode,
+ * top-k + NMS, CBFuse, and the fused letterbox + first conv), 2: the whole step. */
+int cc_yolo_profile_graph(cc_yolo* h, int iters, int which, float* ms_per_replay);
 void cc_yolo_destroy(cc_yolo* h);
 
 /* Single-layer entry used by the parity tests: NHWC conv + bias + optional SiLU on device buffers.
