@@ -219,11 +219,18 @@ def test_detect_f32_matches_oracle_and_golden(size, res, seed, shape, sd_t, sd_c
             assert box_err <= 0.32         # f32 round-off floor actually measured: 0.03-0.17 px
 
 
-def test_decode_topk_nms_exact_given_same_logits(sd_t):
-    """Post-processing isolated: oracle decode+postprocess on the HIP head logits == HIP output row for row."""
+@pytest.mark.parametrize("shift", [0.0, 2.0], ids=["compacted", "radix_select"])
+def test_decode_topk_nms_exact_given_same_logits(sd_t, shift):
+    """Post-processing isolated: oracle decode+postprocess on the HIP head logits == HIP output row for row.  The class-bias shift
+    moves the number of anchors over the 0.25 threshold through the three paths of topk_nms_kernel: fewer than 300 positive anchors
+    (zero-score anchors fill the top-300 in index order), 300-512 (all positives sorted), more than 512 (radix select)."""
+    from clearcam_amd.weights import shift_class_bias
+    sd_t = shift_class_bias(sd_t, shift) if shift else sd_t
     frames = noise_frames(1, 2, 640, 640)
     m = _yolo("t", 640, sd_t, "f32")
     got = m.detect_batch(frames)
+    n_pos = (m.get_tensor("decoded")[..., 4] > 0).sum(1)             # positive anchors per frame: the case exercises the path it is named after
+    assert ((n_pos > 512).any() if shift else ((n_pos < 300).any() and ((n_pos >= 300) & (n_pos <= 512)).any())), n_pos
     raw = [torch.from_numpy(m.get_tensor(f"raw{i}")).permute(0, 3, 1, 2) for i in range(3)]
     o = yo.YOLOv9Oracle("t", 640, sd_t)
     with torch.no_grad():
