@@ -61,7 +61,7 @@ def lib() -> C.CDLL:
         "cc_yolo_get_tensor": [vp, C.c_char_p, vp, i64p, ip],
         "cc_yolo_last_gpu_ms": [vp, fp],
         "cc_yolo_profile": [vp, C.c_int, fp, C.POINTER(C.c_double), ip],
-        "cc_yolo_profile_graph": [vp, C.c_int, fp],
+        "cc_yolo_profile_graph": [vp, C.c_int, C.c_int, fp],
         "cc_conv2d_nhwc": [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, vp, C.c_int, vp],
         "cc_conv_bench": [C.c_int] * 11 + [fp],
