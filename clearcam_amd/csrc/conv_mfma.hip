@@ -736,7 +736,10 @@ static bool halo_legal(const ConvP& p) {
 }
 static bool halo_applicable(const ConvP& p) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("CLEARCAM_HALO"); on = e ? atoi(e) : 1; }
+  // Off by default since round 2: with the single-barrier 128x128 schedule and the eight-wave kernel in place it no longer wins
+  // (whole plan, batch 64: 11.67 ms without it against 11.70 with it; single frame 1.30 against 1.34 ms, where it also kept its
+  // layers off the few-tile configuration because of its (channel slab, tap) K order).  CLEARCAM_HALO=1 brings it back.
+  if (on < 0) { const char* e = getenv("CLEARCAM_HALO"); on = e ? atoi(e) : 0; }
   if (!on || !halo_legal(p)) return false;
   const long covered = (long)((p.Ho + 7) / 8 * 8) * ((p.Wo + 15) / 16 * 16);
   return p.Cin >= 128 && p.Cout % 128 == 0 && (long)p.Ho * p.Wo == covered;
