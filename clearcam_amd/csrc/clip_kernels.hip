@@ -164,7 +164,12 @@ void launch_l2norm(const NormP& p, hipStream_t stream) {
 // 4*NF register values + two cross-lane steps, and the exponentiated P is already in MFMA B-operand layout.
 template <class T, int NF>    // NF = padded keys / 16
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   // two blocks per CU: one wave can run MFMAs while the other does its softmax
-  constexpr int LP = NF * 16, VS = LP + 8;          // padded keys, V^T row stride (elements)
+  // padded keys; V^T row stride (elements).  A ds_read_b128 is served in lane groups that mix two neighbouring k-groups ({0-3, 12-15,
+  // 20-27}, ...): with a pitch of 6 (mod 16) sixteen-byte units - LP + 16 elements for both instantiations - rows of one k-group land on
+  // even units and the other's on odd ones.  LP + 8 (pitch 5 mod 16) had three two-way conflicts per group (SQ_LDS_BANK_CONFLICT was 13 %
+  // of the kernel's wave cycles).
+  constexpr int LP = NF * 16, VS = LP + 16;
+  static_assert((VS * 2 / 16) % 4 == 2, "V^T pitch must be 2 (mod 4) sixteen-byte units");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* ldsK = reinterpret_cast<uint4*>(smem);                         // [LP][8 chunks]
   T* ldsVt = reinterpret_cast<T*>(smem + (size_t)LP * 128);             // [64][VS]
@@ -173,29 +178,47 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
   const int D3 = 3 * p.D;
   const T* base = reinterpret_cast<const T*>(p.qkv) + (size_t)b * p.L * D3 + h * 64;
 
-  // stage K and V^T of this (image, head) ONCE; the workgroup then walks all 64-query tiles
-  for (int idx = tid; idx < LP * 8; idx += 256) {
-    const int key = idx >> 3, chunk = idx & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (key < p.L) {
-      kv = *reinterpret_cast<const uint4*>(base + (size_t)key * D3 + p.D + chunk * 8);
-      vv = *reinterpret_cast<const uint4*>(base + (size_t)key * D3 + 2 * p.D + chunk * 8);
-    }
-    ldsK[key * 8 + (chunk ^ ((key >> 1) & 7))] = kv;
-    // key = 32f + 16hh + 4g + r  ->  position 32f + 8g + 4hh + r  (PV k-slot order, see below)
-    const int pos = (key & ~31) + ((key >> 2) & 3) * 8 + ((key >> 4) & 1) * 4 + (key & 3);
-    const T* ve = reinterpret_cast<const T*>(&vv);
+  // stage K and V^T of this (image, head) ONCE; the workgroup then walks all 64-query tiles.  All loads of a thread are issued
+  // before the first LDS write and none is conditional (keys past L are clamped and zeroed afterwards): with a load inside an
+  // `if (key < L)` per iteration hipcc branched around every load and waited for it before the next one - 2 x 9 dependent round
+  // trips per block (cdna_hip_programming.md, section 5, trap (c)).
+  {
+    constexpr int NIT = LP * 8 / 256;
+    static_assert(LP * 8 % 256 == 0, "whole passes of the 256 threads");
+    uint4 kv[NIT], vv[NIT];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ldsVt[(chunk * 8 + e) * VS + pos] = ve[e];
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 256 * it, key = idx >> 3, chunk = idx & 7, kc = key < p.L ? key : p.L - 1;
+      kv[it] = *reinterpret_cast<const uint4*>(base + (size_t)kc * D3 + p.D + chunk * 8);
+      vv[it] = *reinterpret_cast<const uint4*>(base + (size_t)kc * D3 + 2 * p.D + chunk * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 256 * it, key = idx >> 3, chunk = idx & 7;
+      if (key >= p.L) { kv[it] = make_uint4(0, 0, 0, 0); vv[it] = make_uint4(0, 0, 0, 0); }
+      ldsK[key * 8 + (chunk ^ ((key >> 1) & 7))] = kv[it];
+      // key = 32f + 16hh + 4g + r  ->  position 32f + 8g + 4hh + r  (PV k-slot order, see below)
+      const int pos = (key & ~31) + ((key >> 2) & 3) * 8 + ((key >> 4) & 1) * 4 + (key & 3);
+      const T* ve = reinterpret_cast<const T*>(&vv[it]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ldsVt[(chunk * 8 + e) * VS + pos] = ve[e];
+    }
   }
   __syncthreads();
   const int ql = lane & 15, g = lane >> 4;
+  // Q fragments are loaded one query tile AHEAD (unconditionally: rows past L re-read row L-1, their results are never stored): a
+  // wave otherwise opens every tile with a dependent global load and nothing to do while it is in flight - two waves per SIMD hide
+  // little (SQ counters: the kernel's waves were parked 52 % of their cycles).
+  uint4 qf[2], qn[2];
+  auto load_q = [&](int q0, uint4 (&dst)[2]) {
+    const int qc = q0 + ql < p.L ? q0 + ql : p.L - 1;
+  #pragma unroll
+    for (int ks = 0; ks < 2; ++ks) dst[ks] = *reinterpret_cast<const uint4*>(base + (size_t)qc * D3 + (ks * 4 + g) * 8);
+  };
+  load_q(wave * 16, qf);
   for (int q0 = wave * 16; q0 < p.L; q0 += 64) {
     const int q = q0 + ql;
-    uint4 qf[2];
-  #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      qf[ks] = q < p.L ? *reinterpret_cast<const uint4*>(base + (size_t)q * D3 + (ks * 4 + g) * 8) : make_uint4(0, 0, 0, 0);
+    load_q(q0 + 64 < p.L ? q0 + 64 : q0, qn);
 
     f32x4 s[NF];
   #pragma unroll
@@ -262,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
         *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = make_uint2(pack2<T>(o[d][0] * inv, o[d][1] * inv), pack2<T>(o[d][2] * inv, o[d][3] * inv));
       }
     }
+    qf[0] = qn[0]; qf[1] = qn[1];
   }
 }
 
@@ -301,7 +325,7 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(const AttnP p) {
 }
 
 template <class T, int NF> static void launch_attn_mfma(const AttnP& p, hipStream_t stream) {
-  const size_t lds = (size_t)NF * 16 * 128 + (size_t)64 * (NF * 16 + 8) * sizeof(T);
+  const size_t lds = (size_t)NF * 16 * 128 + (size_t)64 * (NF * 16 + 16) * sizeof(T);
   static bool configured = false;
   if (!configured) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<T, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
