@@ -46,10 +46,14 @@ template <int HID> struct CspGeom {
   static constexpr int TH = 8, TW = 16, PW = TW + 4, PH = TH + 4, PR = PH * PW;   // 12 x 20 = 240 patch pixels
   static constexpr int QW = TW + 2, QH = TH + 2, QR = QH * QW;               // 10 x 18 = 180 ring pixels
   static constexpr int CPA = HID / 8;                                        // 16-byte chunks per row of A, B, T, U
-  // Row pitch of the intermediates: HID channels + 16 bytes of padding.  They are written by ds_write (not by the lane-linear
-  // DMA), so their layout is free: with a pitch of 20 (36) dwords sixteen consecutive rows start on sixteen different 4-bank
-  // groups - conflict-free fragment reads without an XOR swizzle, i.e. every tap of a 3x3 is base + compile-time offset.
-  static constexpr int PA = HID * 2 + 16;
+  // Row pitch of the intermediates: HID channels + 32 bytes of padding.  They are written by ds_write (not by the lane-linear DMA),
+  // so their layout is free, and with padded rows every tap of a 3x3 is base + compile-time offset (no XOR swizzle to recompute).
+  // The pad is chosen for the READS: a ds_read_b128 is served in lane groups that mix two neighbouring k-groups ({0-3, 12-15, 20-27},
+  // ...), and a pitch of 2 (mod 4) sixteen-byte units - 6 at HID 32, 10 at HID 64 - puts sixteen consecutive rows of one k-group on
+  // even units and the other's on odd ones.  (HID*2 + 16, an odd pitch, left three two-way conflicts per group: SQ_LDS_BANK_CONFLICT
+  // was 6-8 % of the kernel's wave cycles.)
+  static constexpr int PA = HID * 2 + 32;
+  static_assert((PA / 16) % 4 == 2, "pitch of the intermediates must be 2 (mod 4) sixteen-byte units");
   static constexpr int X_BYTES = NSLAB * PR * 128, A_BYTES = 256 * PA, B_BYTES = 128 * PA, T_BYTES = 192 * PA, U_BYTES = 128 * PA;
   static constexpr int BIAS_BYTES = (2 * C2 + 2 * HID) * 4;                  // b12 | br | bb | b3 as f32
   static constexpr int SPC = HID == 64 ? 2 : 3;                              // streaming: 3x3 weight slabs per chunk
