@@ -87,7 +87,8 @@ void convert_f32_to(int dt, const float* src, void* dst, size_t n);
 // ---- tensor views (NHWC activations with channel stride) --------------------------------------
 // A Src is one channel range of a conv's input: a channel slice [coff, coff+C) of an NHWC buffer whose
 // pixels hold `cstride` channels.  shift=1 reads the buffer as if nearest-upsampled x2 (Upsample,
-// detection/yolov9.py:285-292 folded into the consumer's loader).
+// detection/yolov9.py:285-292 folded into the consumer's loader).  shift=-1 reads its 2x2 stride-1 AVERAGE (ADown's
+// avg_pool2d(2, 1, 0), :45, folded into the stride-2 conv's loader: conv_adown.hip; the conv's Hin x Win are then (H-1) x (W-1)).
 struct Src {
   const void* ptr; int H, W; int cstride, coff, C; int shift;
 };

@@ -911,6 +911,7 @@ void launch_conv_mfma(int dt, const ConvP& p, hipStream_t stream) {
 }
 
 void launch_conv(int dt, const ConvP& p, hipStream_t stream) {
+  if (p.s0.shift < 0) { launch_conv_adown(dt, p, stream); return; }
   if (conv_mfma_supported(dt, p)) launch_conv_mfma(dt, p, stream);
   else launch_conv_direct(dt, p, stream);
 }

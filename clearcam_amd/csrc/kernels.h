@@ -13,6 +13,9 @@ void launch_conv_mfma(int dt, const ConvP& p, hipStream_t stream);
 void launch_conv_direct(int dt, const ConvP& p, hipStream_t stream);
 // Picks the MFMA kernel when supported, else the direct kernel.
 void launch_conv(int dt, const ConvP& p, hipStream_t stream);
+// 3x3 stride-2 conv over the 2x2 stride-1 average of its source (ConvP::s0.shift == -1; Hin x Win = the averaged map): conv_adown.hip
+bool conv_adown_supported(int dt, const ConvP& p);
+void launch_conv_adown(int dt, const ConvP& p, hipStream_t stream);
 
 // ---- fused RepNCSP block (csp_fused.hip) ----------------------------------------------------------
 // detection/yolov9.py:92-105 with n = 1: cv1 | cv2 (1x1), RepConvN 3x3, 3x3 + shortcut, cv3 (1x1) in one launch; 16-bit

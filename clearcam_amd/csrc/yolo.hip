@@ -180,7 +180,9 @@ struct Builder {
     if (ins.size() > 1) { c.s1 = src(ins[1]); c.s1.ptr = (const void*)(intptr_t)ins[1].v.buf; }
     else { c.s1 = Src{nullptr, 1, 1, 0, 0, 0, 0}; c.s1.ptr = (const void*)(intptr_t)-1; }
     const Buf& b0 = P->bufs[ins[0].v.buf];
-    c.B = P->B; c.Hin = b0.H << ins[0].shift; c.Win = b0.W << ins[0].shift;
+    c.B = P->B;
+    if (ins[0].shift < 0) { c.Hin = b0.H - 1; c.Win = b0.W - 1; }          // the 2x2 stride-1 average of the source (conv_adown.hip)
+    else { c.Hin = b0.H << ins[0].shift; c.Win = b0.W << ins[0].shift; }
     c.Cin = c.s0.C + c.s1.C;
     CC_CHECK(c.Cin == pc.cin, "conv input channels do not match weights");
     if (ins.size() > 1) {
@@ -327,6 +329,15 @@ struct Builder {
     return whole(o);
   }
 
+  // ADown's avg_pool2d(2,1,0) inside the stride-2 conv that reads it (conv_adown.hip; same values, same K order: identical results).
+  // OFF by default - measured slower than the two launches at every shape of the bench plan (0.497 vs 0.182 + 0.199 ms for the
+  // 128-channel half at 160x160, batch 64: the loader pulls every source chunk through L2 nine times instead of 2.25);
+  // CLEARCAM_FUSE_ADOWN=1 turns it on wherever the shape allows.  Read per plan.
+  bool fuse_adown(View in) const {
+    const char* e = getenv("CLEARCAM_FUSE_ADOWN");
+    if (!e || atoi(e) == 0) return false;
+    return Y->dtype != F32 && in.C % 64 == 0 && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0;
+  }
   View down(const std::string& p, View in, int cout) {   // ADown :40-52 / AConv :54-63
     const int H = P->bufs[in.buf].H, W = P->bufs[in.buf].W, C = in.C;
     const int Ho = (H - 1 + 2 - 3) / 2 + 1, Wo = (W - 1 + 2 - 3) / 2 + 1;
@@ -335,9 +346,13 @@ struct Builder {
       CC_CHECK(C == cout, "ADown keeps the channel count");
       // x.avg_pool2d(2,1,0).chunk(2,1): only the half the strided conv reads is materialised at full resolution;
       // the other half goes avg -> max-pool in one pass (avgmax_pool_kernel)
-      const int avg = new_buf(H - 1, W - 1, C / 2);
-      pool(slice(in, 0, C / 2), whole(avg), 2, 1, 0, 0);
-      conv({{whole(avg), 0}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(o), 0, C / 2), 2, 1);
+      if (fuse_adown(slice(in, 0, C / 2))) {
+        conv({{slice(in, 0, C / 2), -1}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(o), 0, C / 2), 2, 1);   // average in the conv's loader
+      } else {
+        const int avg = new_buf(H - 1, W - 1, C / 2);
+        pool(slice(in, 0, C / 2), whole(avg), 2, 1, 0, 0);
+        conv({{whole(avg), 0}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(o), 0, C / 2), 2, 1);
+      }
       const int mp = new_buf(Ho, Wo, C / 2);
       const int E = Y->dtype == F32 ? 4 : 8;
       if ((C / 2) % E == 0 && in.coff % E == 0 && P->bufs[in.buf].C % E == 0) {
@@ -866,9 +881,11 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
         if (op.kind == 0) {
           const ConvP& c = op.conv; const double M = (double)c.B * c.Ho * c.Wo;
           const double es = dtype_size(h->dtype);
-          const double bytes = (double)c.B * (c.Hin >> c.s0.shift) * (c.Win >> c.s0.shift) * c.s0.C * es + (double)c.B * (c.Hin >> c.s1.shift) * (c.Win >> c.s1.shift) * c.s1.C * es
+          const bool avg = c.s0.shift < 0;                 // reads the 2x2 average of its source (conv_adown.hip)
+          const double in0 = avg ? (double)(c.Hin + 1) * (c.Win + 1) : (double)(c.Hin >> c.s0.shift) * (c.Win >> c.s0.shift);
+          const double bytes = (double)c.B * in0 * c.s0.C * es + (double)c.B * (c.Hin >> c.s1.shift) * (c.Win >> c.s1.shift) * c.s1.C * es
                              + M * c.Cout * (c.out_f32 ? 4 : es) + (c.res ? M * c.Cout * es : 0) + (double)c.Cout * c.Ktot * es;
-          fprintf(f, "%zu,conv,%.4f,%.0f,%d,%d,%d,%d,%d,%.4f,%.1f,%.4f,%.0f\n", i, t, M, c.Cout, c.Ktot, c.ks, c.stride, c.Cin,
+          fprintf(f, "%zu,%s,%.4f,%.0f,%d,%d,%d,%d,%d,%.4f,%.1f,%.4f,%.0f\n", i, avg ? "conv_avg" : "conv", t, M, c.Cout, c.Ktot, c.ks, c.stride, c.Cin,
                   op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9);
         } else if (op.kind == 1) {
           const PoolP& q = op.pool; const double es = dtype_size(h->dtype);

@@ -527,3 +527,47 @@ def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fu
     for n in names + ["p3", "p4", "p5", "det"]:
         assert np.array_equal(a[n], b[n]), n
     assert np.abs(a["p3"]).max() > 0.05 and np.isfinite(a["p3"]).all()
+
+
+_ADOWN_SCRIPT = r"""
+import csv, os, sys, numpy as np
+from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict
+from clearcam_amd.yolov9 import YOLOv9
+size, res, dtype, H, W, B, out = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+frames = np.random.default_rng(6).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+sd = conditioned_yolov9_state_dict(size, 1234) if size == "c" else synthetic_yolov9_state_dict(size, 1234)
+m = YOLOv9(size, res, state_dict=sd, dtype=dtype, device=0)
+d = {"det": m.detect_batch(frames)}
+for n in ("p3", "p4", "p5"): d[n] = m.get_tensor(n)
+os.environ["CLEARCAM_PROFILE_CSV"] = out + ".csv"
+m.profile(iters=1)
+kinds = [r["kind"] for r in csv.DictReader(open(out + ".csv"))]
+d["avg_pools"] = np.array(sum(k == "pool0_k2_s1" for k in kinds)); d["avg_convs"] = np.array(sum(k == "conv_avg" for k in kinds))
+np.savez(out, **d)
+"""
+
+
+@pytest.mark.parametrize("size,res,dtype,H,W,B,fused", [
+    ("c", 640, "bf16", 640, 640, 2, 5),      # the bench plan's five ADown blocks: 128- and 256-channel halves, 160x160 ... 40x40 sources
+    ("c", 640, "f16", 270, 480, 1, 5),       # letterboxed 384 x 640: non-square maps, a single frame (fewer tiles than CUs)
+    ("c", 608, "bf16", 608, 608, 3, 5),      # 152 x 152 -> 76 x 76 -> 38 x 38 -> 19 x 19: odd averaged maps, ragged last tiles
+    ("e", 320, "bf16", 320, 320, 1, 8),      # YOLOv9-e: the ADown blocks of both branches
+])
+def test_fused_adown_equals_unfused(tmp_path, size, res, dtype, H, W, B, fused):
+    """conv_avg_s2_kernel (ADown's 2x2 stride-1 average computed in the stride-2 conv's loader) against the two launches it replaces:
+    the averages are summed, scaled and rounded exactly as pool_vec_kernel does and the accumulation runs in the same K order, so
+    P3-P5 and the detections are IDENTICAL, bit for bit, and the averaged map is never materialised (no 2x2 average launches left)."""
+    import subprocess
+    import sys
+    outs = []
+    for lv in ("0", "1"):
+        path = str(tmp_path / f"adown{lv}.npz")
+        env = dict(os.environ, CLEARCAM_FUSE_ADOWN=lv, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", _ADOWN_SCRIPT, size, str(res), dtype, str(H), str(W), str(B), path], check=True, env=env)
+        outs.append(np.load(path))
+    a, b = outs
+    assert int(a["avg_pools"]) == fused and int(a["avg_convs"]) == 0
+    assert int(b["avg_pools"]) == 0 and int(b["avg_convs"]) == fused
+    for n in ("p3", "p4", "p5", "det"):
+        assert np.array_equal(a[n], b[n]), n
+    assert np.abs(a["p3"]).max() > 0.05 and np.isfinite(a["p3"]).all()
