@@ -84,11 +84,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
 // channel c) - 9 contiguous LDS elements per row r - laid into the 32 k slots so that a lane reads whole dwords (see the
 // B-operand comment below).  The result goes through LDS so each pixel's COUT channels leave as 16-byte stores.  HBM traffic: the frames in, the activations out;
 // the (B,Hn,Wn,8) input tensor of the unfused path (a 16-byte write and read per pixel) does not exist.
-template <class T, int COUT>
+// BIG: 36 KB of scratch for the source-byte stage (camera frames scaled down by up to ~3x: 1080p -> 384x640); otherwise 18 KB, which
+// is what the output stage needs (each wave passes its 64 pixels through its own 32-pixel area in two halves) and lets six blocks
+// share a CU instead of three.
+template <class T, int COUT, bool BIG>
 __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
   constexpr int PW = 33, PROW = 104;                     // patch row: 33 pixels x 3 channels (+ pad) in storage type
   constexpr int NT = COUT / 16, OROW = COUT + 8;         // staged output row: COUT channels + 16 bytes (bank spread)
-  constexpr int SCRATCH = 256 * 72 * 2;                  // bytes: the source-pixel stage (phase 1) and the output stage (phase 3) share it
+  constexpr int SCRATCH = (BIG ? 256 : 128) * 72 * 2;    // bytes: the source-pixel stage (phase 1) and the output stage (phase 3) share it
   __shared__ T patch[PW * PROW];
   __shared__ __attribute__((aligned(16))) unsigned char scratch[SCRATCH];
   __shared__ int tab_i[4][PW];                           // xlo, xhi, ylo, yhi of the patch's columns / rows
@@ -231,6 +234,10 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
   int boff[4];                                                        // dword offsets relative to the pixel's first element
 #pragma unroll
   for (int j = 0; j < 4; ++j) boff[j] = kg < 3 ? kg * (PROW / 2) + j : min(j, 2) * (PROW / 2) + 4;
+  // A wave owns tile rows 4*wave .. 4*wave+3 and passes them, two rows at a time, through its own 32-pixel staging area so that every
+  // pixel's COUT channels leave as 16-byte stores: same-wave LDS traffic only, no block barrier after the patch is complete.
+  T* wstage = ostage + wave * (32 * OROW);
+  constexpr int CPP = COUT / 8;                                     // 16-byte chunks per pixel
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int ty = wave * 4 + rr, tx = row;                         // this lane's pixel of the 16-pixel row
@@ -251,17 +258,20 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
         const float xv = acc[i] + bias[nt][i];
         o[i] = (p.abl & 2) ? xv : xv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xv * -1.4426950408889634f));   // SiLU, as conv_mfma's 16-bit epilogue
       }
-      *reinterpret_cast<uint2*>(ostage + (ty * 16 + tx) * OROW + nt * 16 + kg * 4) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+      *reinterpret_cast<uint2*>(wstage + ((rr & 1) * 16 + tx) * OROW + nt * 16 + kg * 4) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
     }
-  }
-  __syncthreads();
-  constexpr int CPP = COUT / 8;                                     // 16-byte chunks per pixel
-  for (int j = tid; j < 256 * CPP; j += 256) {
-    const int px = j / CPP, ch = j - px * CPP, ty = px >> 4, tx = px & 15;
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy < p.Ho && ox < p.Wo)
-      *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride + p.out_coff + ch * 8) =
-          *reinterpret_cast<const uint4*>(ostage + px * OROW + ch * 8);
+    if (rr & 1) {                                                   // two rows staged: store them
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = lane; j < 32 * CPP; j += 64) {
+        const int px = j / CPP, ch = j - px * CPP;
+        const int oy = oy0 + wave * 4 + (rr - 1) + (px >> 4), ox = ox0 + (px & 15);
+        if (oy < p.Ho && ox < p.Wo)
+          *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride + p.out_coff + ch * 8) =
+              *reinterpret_cast<const uint4*>(wstage + px * OROW + ch * 8);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -285,11 +295,19 @@ void stem_pack_weights(int dt, const void* w_packed, int w_row, int cin_pad, int
 
 bool stem_fused_supported(int dt, int Cout) { return dt != F32 && (Cout == 16 || Cout == 32 || Cout == 64); }
 
-template <class T> static void launch_stem_t(const StemP& p, hipStream_t stream) {
+template <class T, bool BIG> static void launch_stem_b(const StemP& p, hipStream_t stream) {
   const dim3 grid((unsigned)((p.Wo + 15) / 16), (unsigned)((p.Ho + 15) / 16), (unsigned)p.pre.B), block(256);
-  if (p.Cout == 64) hipLaunchKernelGGL((stem_fused_kernel<T, 64>), grid, block, 0, stream, p);
-  else if (p.Cout == 32) hipLaunchKernelGGL((stem_fused_kernel<T, 32>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((stem_fused_kernel<T, 16>), grid, block, 0, stream, p);
+  if (p.Cout == 64) hipLaunchKernelGGL((stem_fused_kernel<T, 64, BIG>), grid, block, 0, stream, p);
+  else if (p.Cout == 32) hipLaunchKernelGGL((stem_fused_kernel<T, 32, BIG>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((stem_fused_kernel<T, 16, BIG>), grid, block, 0, stream, p);
+}
+template <class T> static void launch_stem_t(const StemP& p, hipStream_t stream) {
+  // bytes the source rectangle of a 33x33-pixel patch can take in the stage (the kernel checks the exact figure per tile and reads
+  // the frame directly where it does not fit): small scratch, twice the blocks per CU, when that is at most 18 KB
+  const PreP& q = p.pre;
+  const long nr = (33L * q.H + q.nh - 1) / q.nh + 2, nc = (33L * q.W + q.nw - 1) / q.nw + 2;
+  const bool big = !q.frame_f32 && nr * ((nc * 3 + 6) / 4) * 4 > 128 * 72 * 2;
+  if (big) launch_stem_b<T, true>(p, stream); else launch_stem_b<T, false>(p, stream);
 }
 
 void launch_stem_fused(int dt, const StemP& p0, hipStream_t stream) {
