@@ -174,7 +174,7 @@ struct Builder {
   }
 
   // conv op; pointers hold buffer ids until resolve()
-  void conv(const std::vector<In>& ins, const PackedConv& pc, View out, int stride, int act, const View* res = nullptr, int variant = 0) {
+  void conv(const std::vector<In>& ins, const PackedConv& pc, View out, int stride, int act, const View* res = nullptr) {
     Op op{}; op.kind = 0; ConvP& c = op.conv;
     c.s0 = src(ins[0]); c.s0.ptr = (const void*)(intptr_t)ins[0].v.buf;
     if (ins.size() > 1) { c.s1 = src(ins[1]); c.s1.ptr = (const void*)(intptr_t)ins[1].v.buf; }
@@ -198,7 +198,7 @@ struct Builder {
     c.out = (void*)(intptr_t)out.buf; c.out_cstride = ob.C; c.out_coff = out.coff; c.out_f32 = ob.f32;
     if (res) { const Buf& rb = P->bufs[res->buf]; c.res = (const void*)(intptr_t)res->buf; c.res_cstride = rb.C; c.res_coff = res->coff; c.res_f32 = rb.f32; }
     else { c.res = (const void*)(intptr_t)-1; }
-    c.act = act; c.variant = variant;
+    c.act = act;
     op.alg_macs = (double)c.B * c.Ho * c.Wo * pc.macs_px;
     P->ops.push_back(op);
   }
@@ -413,23 +413,7 @@ struct Builder {
       const std::string hb = H22 + "cv2.list." + std::to_string(l) + ".list.", hc = H22 + "cv3.list." + std::to_string(l) + ".list.";
       const int H = P->bufs[feats[l].buf].H, W = P->bufs[feats[l].buf].W, ch = a.cls_hidden;
       const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch), raw = new_buf(H, W, 144, true);
-      // cv2[l][0] (64 box channels) and cv3[l][0] (class channels) read the same feature map and normally run as ONE 64+ch-channel
-      // launch.  On the big maps of a batch that launch is five 64-channel tiles; there the class part on the eight-wave 256x256
-      // kernel plus the box part as 128x64 tiles with three LDS stages (variant 9) is faster and gives the same bits (same K order):
-      // batch 64, per launch, 0.742 -> 0.457 + 0.196 ms at 80x80, 0.387 -> 0.233 + 0.133 at 40x40 (0.129 -> 0.081 + 0.043 at 20x20: a
-      // wash, so maps under 100 k pixels keep the single launch).  CLEARCAM_HEAD_SPLIT: 0 never, 2 always.
-      const char* hs = getenv("CLEARCAM_HEAD_SPLIT");
-      const int hsl = hs ? atoi(hs) : 1;
-      const bool can_split = Y->dtype != F32 && ch % 256 == 0 && hsl != 0;
-      // (the choice depends on the batch size and the host copies of the weights are dropped after cc_yolo_finalize's dry-run build,
-      //  so every form a later plan may ask for is packed whenever a plan is built)
-      const PackedConv& both = pconv({hb + "0.conv", hc + "0.conv"}, {1, 1});
-      if (can_split) { pconv({hc + "0.conv"}, {1}); pconv({hb + "0.conv"}, {1}); }
-      if (can_split && (hsl >= 2 || (long)P->B * H * W >= 100000)) {
-        conv({{feats[l], 0}}, pconv({hc + "0.conv"}, {1}), slice(whole(hbuf), 64, ch), 1, 1);
-        conv({{feats[l], 0}}, pconv({hb + "0.conv"}, {1}), slice(whole(hbuf), 0, 64), 1, 1, nullptr, 9);
-      } else
-      conv({{feats[l], 0}}, both, whole(hbuf), 1, 1);
+      conv({{feats[l], 0}}, pconv({hb + "0.conv", hc + "0.conv"}, {1, 1}), whole(hbuf), 1, 1);
       conv({{slice(whole(hbuf), 0, 64), 0}}, pconv({hb + "1.conv"}, {4}), whole(bxb), 1, 1);
       conv({{slice(whole(hbuf), 64, ch), 0}}, pconv({hc + "1.conv"}, {1}), whole(clb), 1, 1);
       conv({{whole(bxb), 0}}, pconv({hb + "2"}, {4}), slice(whole(raw), 0, 64), 1, 0);
