@@ -34,32 +34,121 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks
 FLOP_PER_FRAME_C640 = 2 * 51.068e9
 
 
-def cpu_baseline(size: str, res: int, seconds: float = 15.0) -> dict:
-    import torch
-    from clearcam_amd.weights import synthetic_yolov9_state_dict
-    from oracle.yolov9_oracle import YOLOv9Oracle
+def _cpu_threads():
     # threads actually used: the host's usable cores, capped (oversubscribing a 256-thread box with one
     # batch-1 conv stream is slower than 16 threads; override with CLEARCAM_CPU_THREADS)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = int(os.environ.get("CLEARCAM_CPU_THREADS", min(avail, 16)))
-    torch.set_num_threads(cores)
-    o = YOLOv9Oracle(size, res, synthetic_yolov9_state_dict(size, 1234))
-    frame = np.random.default_rng(1).integers(0, 256, (res, res, 3), dtype=np.uint8)
-    t0 = time.time()
-    o(frame)                                     # warm-up (also bounds the sample if the host is very slow)
-    warm = time.time() - t0
+    return int(os.environ.get("CLEARCAM_CPU_THREADS", min(avail, 16))), avail
+
+
+def _timed_loop(fn, seconds: float):
+    """fn() once untimed (warm-up, also bounds the sample on a very slow host), then repeated for ~`seconds`."""
+    t0 = time.time(); fn(); warm = time.time() - t0
     n, t0 = 0, time.time()
     while n < 1 or (time.time() - t0 < seconds and (time.time() - t0) + warm < 2 * seconds):
-        o(frame)
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
-            "host_cores_usable": avail, "kind": "port",
-            "sample": f"{n} frames of {res}x{res}, batch 1 (reference semantics), PyTorch-CPU fp32 restatement "
-                      f"of detection/yolov9.py (tinygrad CPU path not runnable offline)"}
+        fn(); n += 1
+    return n, time.time() - t0
+
+
+def cpu_baseline(size: str, res: int, seconds: float = 10.0, with_clip: bool = True) -> dict:
+    """The CPU restatement of the reference (oracle/, PyTorch-CPU fp32 + numpy: tinygrad's CPU path cannot run offline) timed on
+    this host's cores beside every GPU figure of the line: the detector at batch 1 (the reference's call) and
+    batch 8, the ViT-L/14 image tower at batch 1 and 8, and the reference's Python search loop at 10 k / 100 k crops."""
+    import torch
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    from oracle.yolov9_oracle import YOLOv9Oracle
+    cores, avail = _cpu_threads()
+    torch.set_num_threads(cores)
+    o = YOLOv9Oracle(size, res, synthetic_yolov9_state_dict(size, 1234))
+    frames = np.random.default_rng(1).integers(0, 256, (8, res, res, 3), dtype=np.uint8)
+    n1, t1 = _timed_loop(lambda: o(frames[0]), seconds)
+    n8, t8 = _timed_loop(lambda: o.detect_batch(frames), seconds / 2)
+    out = {"value": round(n1 / t1, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+           "host_cores_usable": avail, "kind": "port",
+           "sample": f"{n1} frames of {res}x{res}, batch 1 (reference semantics), PyTorch-CPU fp32 restatement "
+                     f"of detection/yolov9.py (tinygrad CPU path not runnable offline)",
+           "yolo_batch8_frames_per_sec": round(8 * n8 / t8, 3), "yolo_batch8_sample": f"{n8} batches of 8"}
+    if with_clip:
+        from clearcam_amd.arch import CLIP_L14
+        from clearcam_amd.weights import synthetic_clip_state_dict
+        from oracle.clip_oracle import OpenCLIPOracle, search_reference
+        oc = OpenCLIPOracle(synthetic_clip_state_dict(CLIP_L14, 4321), CLIP_L14)
+        x = (np.random.default_rng(2).random((8, 3, 224, 224), dtype=np.float32) * 2 - 1).astype(np.float32)
+        c1, d1 = _timed_loop(lambda: oc.precompute_embedding(x[:1]), seconds / 3)
+        c8, d8 = _timed_loop(lambda: oc.precompute_embedding(x), seconds / 3)
+        out["clip_l14_image_embeds_per_sec"] = {"batch1": round(c1 / d1, 3), "batch8": round(8 * c8 / d8, 3),
+                                                "sample": f"{c1} x batch 1, {c8} x batch 8, oracle/clip_oracle.py (models/objects.py:94-133)"}
+        # the reference's search: a Python loop over a dict of (1,768) arrays, one .item() per crop (models/objects.py:365-390)
+        rng = np.random.default_rng(3)
+        srch = {}
+        for N in (10_000, 100_000):
+            e = rng.standard_normal((N, 768), dtype=np.float32)
+            e /= np.linalg.norm(e, axis=1, keepdims=True)
+            table = {f"data/cameras/cam{i % 8}/objects/2026-01-0{1 + i % 7}/{1700000000 + i}_{i % 5000}_{i % 80}.jpg": e[i:i + 1] for i in range(N)}
+            q = e[7:8].copy()
+            t0 = time.time(); reps = 0
+            while reps < 1 or time.time() - t0 < 1.0:
+                search_reference(table, q, top_k=100); reps += 1
+            srch[f"rows_{N}_ms_per_query"] = round((time.time() - t0) / reps * 1e3, 2)
+        srch["what"] = "oracle.clip_oracle.search_reference (the reference's loop semantics), one query, k=100, single Python thread"
+        out["search_reference_loop"] = srch
+    return out
+
+
+def measured_parity(device_index: int, n_cond: int = 16, n_chaotic: int = 4) -> dict:
+    """Parity numbers computed IN THIS RUN (not quoted from a test log): every storage mode against the f32 CPU oracle on the same
+    seeded frames.  f32 mode on the chaotic checkpoint (~260 detections per frame); f16 / bf16 on the well-conditioned checkpoint,
+    once with 16-bit-exact weights (activation rounding only) and once with the weights un-rounded (the mode's own weight rounding
+    inside the comparison).  A detection counts as matched only with the same class, IoU >= 0.9 AND all four coordinates within
+    1e-3 * max(H, W) px of the oracle's (oracle.yolov9_oracle.match_detections_strict)."""
+    import torch
+    from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict
+    from clearcam_amd.yolov9 import YOLOv9
+    from oracle.yolov9_oracle import YOLOv9Oracle, decoded_rows, parity_summary
+    cores, _ = _cpu_threads()
+    torch.set_num_threads(cores)
+    tol = 1e-3 * 640
+    keys = ("n_ref", "n_got", "n_strict", "match_frac", "match_frac_iou_only", "box_err_px_p50", "box_err_px_p99", "box_err_px_max_strict",
+            "score_err_max", "anchor_box_err_px_p50", "anchor_box_err_px_p99", "anchor_box_err_px_max", "anchor_score_err_max")
+
+    def oracle(sd, frames):
+        o = YOLOv9Oracle("c", 640, sd)
+        det, dec = [], []
+        with torch.no_grad():
+            for i in range(0, len(frames), 4):
+                x = o.network_input(frames[i:i + 4])
+                y = o.decode(o.head_raw(o.features(x)))
+                dec.append(decoded_rows(y))
+                det.append(o.scale_boxes((640, 640), o.postprocess(y), (640, 640)).numpy())
+        return np.concatenate(det), np.concatenate(dec)
+
+    def hip(sd, frames, dtype):
+        m = YOLOv9("c", 640, state_dict=sd, dtype=dtype, device=device_index)
+        got = m.detect_batch(frames)
+        dec = m.get_tensor("decoded")
+        m.close()
+        return got, dec
+
+    def summary(ref, got):
+        s = parity_summary(ref[0], got[0], tol, ref[1], got[1])
+        return {k: (round(s[k], 5) if isinstance(s[k], float) else s[k]) for k in keys}
+
+    out = {"how": "measured in this run against the f32 CPU oracle on the same seeded frames; matched = same class, IoU >= 0.9 and all four "
+                  "coordinates within 1e-3*max(H,W) = 0.64 px; anchor_* = the same anchor's decoded box / score wherever both sides score it over 0.25",
+           "box_tol_px": tol}
+    fr = np.random.default_rng(1).integers(0, 256, (n_chaotic, 640, 640, 3), dtype=np.uint8)
+    sd = synthetic_yolov9_state_dict("c", 1234)
+    out["f32_chaotic_checkpoint"] = dict(summary(oracle(sd, fr), hip(sd, fr, "f32")), frames=n_chaotic)
+    fr = np.random.default_rng(1).integers(0, 256, (n_cond, 640, 640, 3), dtype=np.uint8)
+    for label, exact in (("weights_16bit_exact", True), ("weights_unrounded", False)):
+        sd = conditioned_yolov9_state_dict("c", 1234, exact=exact)
+        ref = oracle(sd, fr)
+        out[label] = {dt: summary(ref, hip(sd, fr, dt)) for dt in ("f16", "bf16")}
+        out[label]["frames"] = n_cond
+    return out
 
 
 def clip_side_metrics(device_index: int, dev) -> dict:
@@ -288,7 +377,10 @@ def main() -> None:
     ap.add_argument("--res", type=int, default=640)
     ap.add_argument("--height", type=int, default=0, help="source frame height (default: res)")
     ap.add_argument("--width", type=int, default=0, help="source frame width (default: res)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f32"],
+                    help="storage / MFMA operand type.  f16 is the default: it is the 16-bit mode that meets the f32 gate's own parity yardstick "
+                         "(bf16's 8 significant bits cannot; DESIGN.md section 5), at the same MFMA rate")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement against the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clip", action="store_true", help="skip the CLIP / search side metrics")
     ap.add_argument("--no-streams", action="store_true", help="skip the camera-pipeline side metrics (detect -> OC-SORT incl. PCIe)")
@@ -346,6 +438,21 @@ def main() -> None:
         return dt
 
     elapsed = timed(model, args.steps, args.warmup)
+    # What the collective backend actually saw: an all-reduce of ones (= the number of ranks that took part) and every rank's own
+    # K-step time, so that the driver's scaling record can check "N ranks over RCCL" against the line instead of trusting --gpus.
+    ranks_seen, per_rank_ms = 1, None
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+        sync(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.detect_batch_device(frames, out)
+        sync()
+        mine = torch.zeros(world, dtype=torch.float64, device=dev)
+        mine[rank] = (time.perf_counter() - t0) / args.steps * 1e3
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(v), 3) for v in mine.tolist()]
     n_det = int((out[..., 4] > 0).sum().item())
 
     # >= 100 timed iterations, median.  Per-step wall times on this rank (each step synchronised), next to
@@ -444,6 +551,12 @@ def main() -> None:
         except Exception:                         # noqa: BLE001  the table is a convenience, never fatal
             pass
         alg_flops = 2.0 * prof["alg_macs_per_step"]
+        parity = None
+        if on_gpu and not args.no_parity:
+            try:
+                parity = measured_parity(local)
+            except Exception as exc:             # noqa: BLE001  a side measurement must not take the headline down
+                parity = {"error": f"{type(exc).__name__}: {exc}"}
         # Conv time per step as the launches run in production (inside the plan's hipGraph), with ONE hipEvent pair per measurement
         # instead of an event record between every two launches (2-3 us each, ~0.3 ms per step of measurement overhead in the
         # per-launch table above):  in-plan conv time = whole step replayed - every non-conv launch replayed.  The conv launches
@@ -454,12 +567,22 @@ def main() -> None:
             g_all, g_other, g_conv = model.profile_graph(2, 10), model.profile_graph(1, 10), model.profile_graph(0, 10)
         except Exception:                         # noqa: BLE001  older library / mocked model
             pass
-        conv_s = ((g_all - g_other) if g_all and g_other else prof["conv_ms"]) * 1e-3
-        achieved = alg_flops / conv_s / 1e12
-        peak = PEAK_TFLOPS[args.dtype]
-        default_cfg = (args.size, args.res, B, args.dtype, fh, fw) == ("c", 640, 64, "bf16", 640, 640)
+        default_cfg = (args.size, args.res, B, args.dtype, fh, fw) == ("c", 640, 64, "f16", 640, 640)
         traffic, traffic_note = measured_traffic(default_cfg)
         traced = traced_kernel_ms(default_cfg)
+        peak = PEAK_TFLOPS[args.dtype]
+        # `achieved` / `frac`: the conv kernels' time per step from rocprofv3's own kernel durations when the committed trace was taken
+        # from exactly these kernels (profiles/kernel_trace.json, digest-checked); otherwise the live in-plan measurement (graph
+        # subtraction), otherwise the eager per-launch event sum.  All three are always reported side by side; `frac_source` says
+        # which one `frac` is.
+        live_s = ((g_all - g_other) if g_all and g_other else prof["conv_ms"]) * 1e-3
+        if traced:
+            conv_s, frac_source = traced["conv_ms_per_step"] * 1e-3, "rocprofv3 kernel durations (profiles/kernel_trace.json, same kernel sources by digest)"
+        elif g_all and g_other:
+            conv_s, frac_source = live_s, "live: whole-step hipGraph minus non-conv-launch hipGraph (no rocprofv3 trace of these kernel sources committed)"
+        else:
+            conv_s, frac_source = live_s, "live: sum of per-launch hipEvent pairs, eager replay (graph profile unavailable)"
+        achieved = alg_flops / conv_s / 1e12
         line = {
             "metric": f"yolov9{args.size}_{args.res}x{args.res}_frames_per_sec" if (fh, fw) == (args.res, args.res)
                       else f"yolov9{args.size}_{fh}x{fw}_letterbox{args.res}_frames_per_sec",
@@ -471,23 +594,21 @@ def main() -> None:
                                    f"(letterbox+convs+decode+top300+NMS)",
                        "batch_per_gpu": B, "parallelism": f"one camera batch per GPU x{world}, no collective",
                        "detections_last_batch": n_det},
-            "parity": {"f32": "every oracle detection matched one-to-one (class, IoU >= 0.9), boxes within 1e-3 x max(H,W) px and scores within "
-                              "1e-3 - north_star's unitless 'box coords within 1e-3' read in image-normalised units (this repo's reading; "
-                              "1e-3 px absolute is below f32 round-off of a 144-conv network); measured 0.03-0.17 px",
-                       "bf16_f16": "well-conditioned synthetic checkpoint (perturbation gain ~1, bf16-exact weights) at this batch and size: >= 95 % "
-                                   "one-to-one matches at IoU >= 0.9, per-anchor scores within 1e-2, P3/P4/P5 rel-RMS <= 3e-2 (bf16) / 4e-3 (f16); "
-                                   "measured bf16 96.3 %, f16 99.6 % (tests/test_gpu_yolo.py, __graft_entry__.smoke)",
-                       "frames_per_sec_by_storage_dtype": precisions},
+            "parity": parity,
+            "frames_per_sec_by_storage_dtype": precisions,
+            "ranks_seen": ranks_seen, "ms_per_step_by_rank": per_rank_ms,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4),
+                         "frac": round(achieved / peak, 4), "frac_source": frac_source,
+                         "frac_live_graph_subtraction": round(alg_flops / live_s / 1e12 / peak, 4),
                          # the bandwidth-side fraction, unfused activation traffic (380.6 MB/frame bf16 at 640x640) over 8 TB/s
                          "hbm_side_frac": round(fps / world * 380.6e6 / 8e12, 4) if (fh, fw, args.res, args.size) == (640, 640, 640, "c") else None,
                          "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "conv kernels (every conv launch of the plan incl. the fused RepNCSP launches; the fused letterbox + first conv is reported under other_ms_per_step)",
                          "alg_gflop_per_step": round(alg_flops / 1e9, 2), "kernel_ms_per_step": round(conv_s * 1e3, 3),
-                         "kernel_ms_per_step_how": "whole step replayed as a hipGraph minus the non-conv launches replayed as a hipGraph, one hipEvent pair around "
-                                                   "10 replays each (the conv launches' time inside the plan, inter-kernel gaps included)"
-                                                   if g_all and g_other else "sum of per-launch hipEvent pairs (eager replay)",
+                         "kernel_ms_per_step_live": round(live_s * 1e3, 3),
+                         "kernel_ms_per_step_live_how": "whole step replayed as a hipGraph minus the non-conv launches replayed as a hipGraph, one hipEvent pair around "
+                                                        "10 replays each (the conv launches' time inside the plan, inter-kernel gaps included)"
+                                                        if g_all and g_other else "sum of per-launch hipEvent pairs (eager replay)",
                          "graph_ms": {"whole_step": round(g_all, 3), "non_conv_launches": round(g_other, 3), "conv_launches_alone": round(g_conv, 3)} if g_all else None,
                          "kernel_ms_per_step_eager_events": round(prof["conv_ms"], 3),
                          # the referee: rocprofv3's own kernel durations for the same launches (under the profiler the chip clocks ~2 % lower)
@@ -526,7 +647,7 @@ def main() -> None:
         if sharded is not None:
             line["search_sharded"] = sharded
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.size, args.res)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.res, with_clip=not args.no_clip)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

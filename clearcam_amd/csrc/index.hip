@@ -424,6 +424,10 @@ int cc_index_add_grouped(cc_index* h, const float* emb, int64_t n, int on_device
       const size_t cnt = (size_t)n * h->dim;
       const float* src = emb; float* tmp = nullptr;
       if (!on_device) { CC_HIP(hipMalloc((void**)&tmp, cnt * 4)); CC_HIP(hipMemcpy(tmp, emb, cnt * 4, hipMemcpyHostToDevice)); src = tmp; }
+      // Device-resident rows may still be being written by the caller's stream (torch's, not ours): the conversion kernel runs on
+      // the index's private non-blocking stream, which nothing orders behind that producer.  The f32 path is ordered by its
+      // blocking hipMemcpy; here the producer is waited for explicitly (add is not a hot path).
+      else CC_HIP(hipDeviceSynchronize());
       hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 65535)), dim3(256), 0, h->stream, src, reinterpret_cast<uint16_t*>(dst), cnt);
       CC_HIP(hipStreamSynchronize(h->stream));
       if (tmp) hipFree(tmp);

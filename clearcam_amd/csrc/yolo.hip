@@ -250,15 +250,20 @@ struct Builder {
   int dimH(const In& in) { return P->bufs[in.v.buf].H << in.shift; }
   int dimW(const In& in) { return P->bufs[in.v.buf].W << in.shift; }
 
-  // The four launches of a RepNCSP with one bottleneck as one kernel (csp_fused.hip); 16-bit storage.  Default: hidden width 32
-  // (weights resident in LDS, 2x the four launches); CLEARCAM_FUSE_CSP=2 also takes hidden width 64 (weights streamed: measured
-  // slower than the four launches), =0 keeps the layer-at-a-time path everywhere.  Read per plan, so a test can build both in
-  // one process.
+  // The four launches of a RepNCSP with one bottleneck as one kernel (csp_fused.hip); 16-bit storage.  Default (level 2): hidden
+  // widths 32 (weights resident in LDS: 0.296 ms against 0.394 for the four launches at 160x160) and 64 (weights streamed
+  // through a two-slot ring: 0.225 against 0.239 at 80x80); CLEARCAM_FUSE_CSP=1 fuses hidden 32 only, =0
+  // keeps the layer-at-a-time path everywhere.  Read per plan, so a test can build both in one process.
+  // Development-only switches are honoured only under CLEARCAM_DEV=1.
+  static const char* dev_env(const char* name) {
+    static const bool dev = [] { const char* e = getenv("CLEARCAM_DEV"); return e && atoi(e) != 0; }();
+    return dev ? getenv(name) : nullptr;
+  }
   bool fuse_csp(View in, int hid, int index) const {
     const char* e = getenv("CLEARCAM_FUSE_CSP");
     const int level = e ? atoi(e) : 2;
     if (level == 0 || (level == 1 && hid != 32)) return false;
-    const char* only = getenv("CLEARCAM_CSP_ONLY");                 // development: fuse just this block (csp_debug.py)
+    const char* only = dev_env("CLEARCAM_CSP_ONLY");                // development: fuse just this block (csp_debug.py)
     if (only && atoi(only) != index) return false;
     return a.rep_n == 1 && csp_fused_supported(Y->dtype, hid) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0;
   }
@@ -276,8 +281,8 @@ struct Builder {
     q.w12 = c12.w; q.kw12 = c12.kw; q.b12 = c12.bias; q.wr = cr.w; q.kwr = cr.kw; q.br = cr.bias;
     q.wb = cb.w; q.kwb = cb.kw; q.bb = cb.bias; q.w3 = c3.w; q.kw3 = c3.kw; q.b3 = c3.bias;
     q.B = P->B; q.H = ib.H; q.W = ib.W; q.hid = hid;
-    { const char* e = getenv("CLEARCAM_CSP_DBG"); q.dbg = e ? atoi(e) : 0; }
-    { const char* e = getenv("CLEARCAM_CSP_STREAM"); q.stream = e ? atoi(e) : 0; }
+    { const char* e = dev_env("CLEARCAM_CSP_DBG"); q.dbg = e ? atoi(e) : 0; }       // stops the kernel after stage 1-3: WRONG outputs
+    { const char* e = dev_env("CLEARCAM_CSP_STREAM"); q.stream = e ? atoi(e) : 0; }
     op.alg_macs = (double)P->B * ib.H * ib.W * (c12.macs_px + cr.macs_px + cb.macs_px + c3.macs_px);
     P->ops.push_back(op);
   }

@@ -177,8 +177,12 @@ class EmbeddingIndex:
         for callers that keep going on the device (clearcam_amd.dist.ShardedIndex: all-gather + merge)."""
         import torch
         dev = torch.device("cuda", self.device)
-        on_dev = bool(getattr(q, "is_cuda", False))
-        qa = q.contiguous().float().reshape(-1, self.dim) if on_dev else np.ascontiguousarray(as_numpy(q), dtype=np.float32).reshape(-1, self.dim)
+        if not bool(getattr(q, "is_cuda", False)):
+            # on_device=1 tells the library that BOTH the queries and the outputs are device pointers: a host query is uploaded
+            # here first, on the caller's stream (a host pointer handed to a device-to-device copy only works by accident of
+            # ROCm's pointer inference, and the temporary could be freed while the copy is pending)
+            q = torch.as_tensor(np.ascontiguousarray(as_numpy(q), dtype=np.float32)).to(dev)
+        qa = q.contiguous().float().reshape(-1, self.dim)
         idx = torch.empty((qa.shape[0], k), dtype=torch.int32, device=dev)
         sc = torch.empty((qa.shape[0], k), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream

@@ -259,12 +259,17 @@ def unpack_cond_table(size: str, gain: np.ndarray, bias: np.ndarray, jitter: np.
     return table
 
 
-def conditioned_yolov9_state_dict(size: str = "c", seed: int = 1234, table=None) -> Dict[str, np.ndarray]:
+def conditioned_yolov9_state_dict(size: str = "c", seed: int = 1234, table=None, exact: bool = True) -> Dict[str, np.ndarray]:
     """Seeded, well-conditioned YOLOv9 state dict (same keys and shapes as the reference's checkpoints).
 
     weight = base filter x gain[conv] (x per-class gain in the head), rounded to values bf16 and f16 hold exactly;
     bias = jitter[conv] x seeded N(0,1) + shift[conv][channel].  `table` (tests / the calibration tool) overrides the
-    committed assets/synth_cond_<size>.npz."""
+    committed assets/synth_cond_<size>.npz.
+
+    exact=False keeps the float32 products un-rounded, so that a 16-bit mode's re-quantisation of the WEIGHTS is part of
+    what a comparison with the f32 oracle measures (as with a trained f32 checkpoint).  On this network that term is
+    the larger one by construction: its 3x3 filters are low-pass, which attenuates white activation-rounding noise at
+    every layer but passes the smooth, signal-correlated error of a perturbed filter (per-block table in DESIGN.md section 5)."""
     if table is None:
         if size not in _COND:
             import os
@@ -280,7 +285,7 @@ def conditioned_yolov9_state_dict(size: str = "c", seed: int = 1234, table=None)
             continue
         prefix = key[:-len(".weight")]
         gain = np.asarray(table.get("g:" + prefix, 1.0), np.float32).reshape(-1, 1, 1, 1)
-        sd[key] = _storage_exact(sd[key] * gain)
+        sd[key] = _storage_exact(sd[key] * gain) if exact else (sd[key] * gain).astype(np.float32)
         jitter = np.float32(table.get("j:" + prefix, 0.0))
         shift = np.asarray(table.get("b:" + prefix, 0.0), np.float32)
         sd[prefix + ".bias"] = (sd[prefix + ".bias"] * jitter + shift).astype(np.float32)

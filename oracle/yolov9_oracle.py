@@ -369,3 +369,62 @@ def match_detections(ref: np.ndarray, got: np.ndarray, iou_thr: float = 0.9):
             box_err = max(box_err, float(np.abs(row[:4] - g[bj][:4]).max()))
             sc_err = max(sc_err, float(abs(row[4] - g[bj][4])))
     return len(r), len(g), n, box_err, sc_err
+
+
+def match_detections_strict(ref: np.ndarray, got: np.ndarray, box_tol: float, iou_thr: float = 0.9):
+    """The yardstick of the f32 gate applied pair by pair: a detection is matched only if a detection of the same class with
+    IoU >= iou_thr exists on the other side AND its four coordinates lie within `box_tol` pixels (north_star's 1e-3 read as
+    1e-3 * max(H, W)).  A pair that clears the IoU bar with a larger coordinate error is a different anchor that survived NMS
+    among heavily overlapping candidates - a selection flip, counted as unmatched, not as a small error.
+
+    Returns a dict: n_ref, n_got, n_iou (pairs at IoU >= thr), n_strict (pairs also within box_tol), box_err (sorted array of
+    the coordinate errors of the IoU pairs), score_err_max (over strict pairs)."""
+    r = ref[ref[:, 4] > 0]
+    g = got[got[:, 4] > 0]
+    used = np.zeros(len(g), bool)
+    errs, n_strict, sc = [], 0, 0.0
+    for row in r:
+        cand = np.nonzero(~used & (g[:, 5].astype(np.int64) == int(row[5])))[0]
+        if not len(cand):
+            continue
+        c = g[cand]
+        ix = np.clip(np.minimum(row[2], c[:, 2]) - np.maximum(row[0], c[:, 0]), 0, None)
+        iy = np.clip(np.minimum(row[3], c[:, 3]) - np.maximum(row[1], c[:, 1]), 0, None)
+        inter = ix * iy
+        u = (row[2] - row[0]) * (row[3] - row[1]) + (c[:, 2] - c[:, 0]) * (c[:, 3] - c[:, 1]) - inter
+        iou = np.where(u > 0, inter / np.where(u > 0, u, 1), 0.0)
+        j = int(np.argmax(iou))
+        if iou[j] >= iou_thr:
+            used[cand[j]] = True
+            e = float(np.abs(row[:4] - c[j, :4]).max())
+            errs.append(e)
+            if e <= box_tol:
+                n_strict += 1
+                sc = max(sc, float(abs(row[4] - c[j, 4])))
+    return {"n_ref": len(r), "n_got": len(g), "n_iou": len(errs), "n_strict": n_strict,
+            "box_err": np.sort(np.asarray(errs, np.float64)), "score_err_max": sc}
+
+
+def parity_summary(refs: np.ndarray, gots: np.ndarray, box_tol: float, dec_ref: np.ndarray = None, dec_got: np.ndarray = None) -> dict:
+    """match_detections_strict over a batch, plus (when the per-anchor decoded rows of both sides are given) the continuous
+    quantity behind it: coordinate error anchor by anchor over the anchors both sides score over the threshold."""
+    tot = {"n_ref": 0, "n_got": 0, "n_iou": 0, "n_strict": 0}
+    errs, sc = [], 0.0
+    for a, b in zip(refs, gots):
+        m = match_detections_strict(a, b, box_tol)
+        for k in tot:
+            tot[k] += m[k]
+        errs.append(m["box_err"]); sc = max(sc, m["score_err_max"])
+    errs = np.sort(np.concatenate(errs)) if errs else np.zeros(0)
+    den = max(tot["n_ref"], tot["n_got"], 1)
+    out = dict(tot, match_frac=tot["n_strict"] / den, match_frac_iou_only=tot["n_iou"] / den, box_tol_px=box_tol, score_err_max=sc,
+               box_err_px_p50=float(np.quantile(errs, 0.5)) if len(errs) else 0.0, box_err_px_p99=float(np.quantile(errs, 0.99)) if len(errs) else 0.0,
+               box_err_px_max_strict=float(errs[errs <= box_tol].max()) if (errs <= box_tol).any() else 0.0,
+               box_err_px_max_iou_pairs=float(errs.max()) if len(errs) else 0.0)
+    if dec_ref is not None and dec_got is not None:
+        both = (dec_ref[..., 4] > 0) & (dec_got[..., 4] > 0)
+        ae = np.abs(dec_ref[..., :4] - dec_got[..., :4]).max(-1)[both]
+        out.update(anchors_both_over_thr=int(both.sum()), anchor_box_err_px_p50=float(np.quantile(ae, 0.5)) if len(ae) else 0.0,
+                   anchor_box_err_px_p99=float(np.quantile(ae, 0.99)) if len(ae) else 0.0, anchor_box_err_px_max=float(ae.max()) if len(ae) else 0.0,
+                   anchor_score_err_max=float(np.abs(dec_ref[..., 4] - dec_got[..., 4])[both].max()) if both.any() else 0.0)
+    return out

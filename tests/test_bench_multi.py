@@ -36,6 +36,10 @@ def test_two_ranks_produce_one_weak_scaling_line():
     sh = line["search_sharded"]
     assert sh["rows_total"] == 4000 and sh["rows_per_gpu"] == 2000 and sh["ranks_ok"] == 2 and sh["result_sorted_and_in_range"] is True
     assert "roofline" in line and "cpu_baseline" not in line     # the CPU leg runs at N=1 only
+    # what the collective backend saw: an all-reduce of ones over the ranks, and every rank's own step time (rank 1 is the slow one)
+    assert line["ranks_seen"] == 2
+    pr = line["ms_per_step_by_rank"]
+    assert len(pr) == 2 and all(v > 0 for v in pr) and pr[1] >= 2.0 and pr[1] <= line["ms_per_step"] * 1.5 + 1.0
 
 
 def test_a_failing_side_metric_on_one_rank_does_not_hang_or_kill_the_line():

@@ -341,6 +341,34 @@ def test_bf16_index_scores_within_1e_3():
         assert (np.diff(scb[r]) <= 0).all()
 
 
+def test_bf16_index_add_is_ordered_behind_an_asynchronous_producer():
+    """Rows handed over as a CUDA tensor that torch's stream is still writing (randn -> normalise, no sync) must be converted
+    AFTER the producer finished: the conversion kernel runs on the index's own non-blocking stream.  A host query through
+    search_device is uploaded on the caller's stream first (the C ABI's on_device flag covers query AND outputs)."""
+    import torch
+    from clearcam_amd.objects import EmbeddingIndex
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    b = EmbeddingIndex(768, 1000, storage="bf16")
+    chunks = []
+    for _ in range(4):
+        big = torch.randn(8192, 8192, device=dev, generator=g)
+        junk = (big @ big).sum()                                           # ~10 ms of queued work ahead of the producer
+        e = torch.randn(60000, 768, device=dev, generator=g) + junk * 0
+        e = e / e.norm(dim=1, keepdim=True)
+        b.add(e)                                                           # no synchronize: the library must order itself
+        chunks.append(e)
+    E = torch.cat(chunks)
+    q = torch.randn(3, 768, generator=torch.Generator().manual_seed(1)); q /= q.norm(dim=1, keepdim=True)
+    want = q.to(dev) @ E.to(torch.bfloat16).float().T
+    got = torch.from_numpy(b.scores(q.numpy())).to(dev)
+    assert float((got - want).abs().max()) <= 2e-5
+    idx_d, sc_d = b.search_device(q.numpy(), 10)                            # host query, device results
+    idx_h, sc_h = b.search(q.numpy(), 10)
+    assert np.array_equal(idx_d.cpu().numpy(), idx_h) and np.allclose(sc_d.cpu().numpy(), sc_h, atol=1e-6)
+    b.close()
+
+
 def test_sharded_index_over_rccl_world_size_1():
     """The RCCL plumbing of the N>1 search path on real hardware (one rank): nccl init, shard offsets, the device-resident
     all-gather + merge of ShardedIndex and the padded all-gather of ReplicatedIndex, against the local HIP index."""

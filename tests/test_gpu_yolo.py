@@ -6,8 +6,9 @@ Tolerances (BASELINE.json north_star: "box coords/classes within 1e-3"):
     matched one-to-one by class and IoU >= 0.9.  Measured: 0.03 px / 5e-5 — the f32 round-off floor
     of a 144-conv network between two different summation orders.
   * f16/bf16 (speed modes) are checked per layer to storage-rounding tolerance and end to end on the
-    well-conditioned synthetic checkpoint (perturbation gain ~1, weights bf16-exact): >= 95 % one-to-one
-    matches at IoU >= 0.9, scores within 1e-2, P3..P5 within 3e-2 / 4e-3 relative RMS, at B=64 640x640.
+    well-conditioned synthetic checkpoint (perturbation gain ~1) at B=64 640x640.  f16 - the dtype bench.py
+    defaults to - is held to the f32 gate's own yardstick (>= 99 % of the detections matched with boxes within
+    1e-3 * max(H, W)); bf16 to its own stated bars; a second run keeps the weights un-rounded (see BARS_16BIT).
     The chaotic checkpoint (gain 30-60x) is kept for the f32 gate, where its ~260 detections per frame
     give top-k / NMS real work; its 16-bit end-to-end test is only a guard against gross breakage.
 """
@@ -243,16 +244,29 @@ def test_decode_topk_nms_exact_given_same_logits(sd_t, shift):
 
 
 # End-to-end bars of the 16-bit storage modes on the WELL-CONDITIONED checkpoint (clearcam_amd/weights.py
-# conditioned_yolov9_state_dict; measured conditioning in clearcam_amd/assets/synth_cond_report.json): at the bench
-# configuration (YOLOv9-C, B=64, 640x640) >= 95 % of the detections match the f32 oracle one-to-one by class and IoU >= 0.9,
-# scores within 1e-2, P3/P4/P5 within 3e-2 (bf16) / 4e-3 (f16) relative RMS.
+# conditioned_yolov9_state_dict; measured conditioning in clearcam_amd/assets/synth_cond_report.json), at the bench
+# configuration (YOLOv9-C, B=64, 640x640).  The yardstick is the f32 gate's own: a detection is matched only when a detection of
+# the same class with IoU >= 0.9 AND all four coordinates within 1e-3 * max(H, W) px exists on the other side
+# (oracle.match_detections_strict), and the continuous quantity behind it - the decoded box of one and the same anchor - is held to
+# the same 1e-3 * max(H, W) wherever both sides score the anchor over the threshold.
+#   f16  (the headline dtype of bench.py): >= 99 % matched, per-anchor boxes within 1e-3 * max(H, W), scores within 2e-3,
+#        P3/P4/P5 within 4e-3 relative RMS.   CPU emulation of the storage roundings (tools/dev/mixed_eval.py, 64 frames): 99.2 %
+#        matched, per-anchor max 0.45 px, p99 0.22 px.
+#   bf16 cannot meet that yardstick on any network: 8 significant bits are 4e-3 relative per rounding, the bar is 1e-3 of the image
+#        for boxes that span most of it.  Emulation: 96.5 % of the IoU pairs within 0.64 px, per-anchor p50 0.13 / p99 1.5 / max
+#        4.6 px - and keeping DDetect's box branch in f32 changes nothing (the error arrives with P3..P5).  It stays a speed mode
+#        with its own, stated bars: >= 90 % strict matches, >= 95 % IoU matches, per-anchor median within 1e-3 * max(H, W),
+#        scores within 1e-2, P3/P4/P5 within 3e-2.
 BARS_16BIT = {"bf16": 3e-2, "f16": 4e-3}
+MATCH_16BIT = {"bf16": 0.90, "f16": 0.99}
+SCORE_16BIT = {"bf16": 1e-2, "f16": 2e-3}
 
 
-def conditioned_case(frames, chunk=8):
-    """f32 oracle over `frames` in chunks (CPU memory): detections (B,300,6), P3/P4/P5 as NHWC arrays, decoded rows (B,A,6)."""
+def conditioned_case(frames, chunk=8, exact=True, emulate=()):
+    """f32 oracle over `frames` in chunks (CPU memory): detections (B,300,6), P3/P4/P5 as NHWC arrays, decoded rows (B,A,6).
+    `emulate`: storage types whose rounding emulation (oracle/lowprec_oracle.py) is run on the same frames -> {dtype: (det, dec)}."""
     from clearcam_amd.weights import conditioned_yolov9_state_dict
-    sd = conditioned_yolov9_state_dict("c", 1234)
+    sd = conditioned_yolov9_state_dict("c", 1234, exact=exact)
     res = max(frames.shape[1:3])
     o = yo.YOLOv9Oracle("c", res, sd)
     det, dec, feats = [], [], [[], [], []]
@@ -265,41 +279,83 @@ def conditioned_case(frames, chunk=8):
             det.append(o.scale_boxes(tuple(x.shape[2:]), o.postprocess(y), frames.shape[1:3]).numpy())
             for l in range(3):
                 feats[l].append(f[l].permute(0, 2, 3, 1).numpy())
-    return sd, np.concatenate(det), [np.concatenate(f) for f in feats], np.concatenate(dec)
+    out = [sd, np.concatenate(det), [np.concatenate(f) for f in feats], np.concatenate(dec)]
+    if emulate:
+        from oracle.lowprec_oracle import LowPrecOracle
+        emu = {}
+        for dt in emulate:
+            lo = LowPrecOracle("c", res, sd, dt)
+            d2, c2 = [], []
+            with torch.no_grad():
+                for i in range(0, len(frames), chunk):
+                    x = lo.network_input(frames[i:i + chunk])
+                    y = lo.decode(lo.head_raw(lo.features(x)))
+                    c2.append(yo.decoded_rows(y))
+                    d2.append(lo.scale_boxes(tuple(x.shape[2:]), lo.postprocess(y), frames.shape[1:3]).numpy())
+            emu[dt] = (np.concatenate(d2), np.concatenate(c2))
+        out.append(emu)
+    return out
 
 
 def check_16bit_against_oracle(m, dtype, frames, ref, feats, dec_ref, min_dets):
-    """The bars of the 16-bit modes: features, per-anchor scores of every candidate, one-to-one detection matches."""
+    """The bars of the 16-bit modes: features, per-anchor scores and boxes of every candidate, strict one-to-one matches."""
     got = m.detect_batch(frames)
+    tol = 1e-3 * max(frames.shape[1:3])
     for name, r in zip(("p3", "p4", "p5"), feats):
         rel = np.sqrt(((m.get_tensor(name) - r) ** 2).mean() / (r ** 2).mean())
         assert rel <= BARS_16BIT[dtype], (dtype, name, rel)
-    # scores within 1e-2, anchor by anchor, for every anchor either side scores over the threshold (the other side's
+    # scores anchor by anchor, for every anchor either side scores over the threshold (the other side's
     # thresholded score may read 0 when it lands just under 0.25: compare those against the threshold itself)
     dec = m.get_tensor("decoded")
     a, b = dec_ref[..., 4], dec[..., 4]
     cand = (a > 0) | (b > 0)
     same_cls = (dec_ref[..., 5] == dec[..., 5]) | (a == 0) | (b == 0)
     sc_err = np.abs(np.where(a > 0, a, 0.25) - np.where(b > 0, b, 0.25))[cand & same_cls].max()
-    assert cand.sum() >= min_dets and sc_err <= 1e-2, (dtype, sc_err)
+    assert cand.sum() >= min_dets and sc_err <= SCORE_16BIT[dtype], (dtype, sc_err)
     assert (same_cls[cand]).mean() >= 0.99                                   # argmax flips only between near-tied classes
-    n_ref = n_got = n_match = 0
-    for i in range(len(frames)):
-        x, y, k, _, _ = yo.match_detections(ref[i], got[i], 0.9)
-        n_ref += x; n_got += y; n_match += k
-    assert n_ref >= min_dets, n_ref
-    assert n_match >= 0.95 * max(n_ref, n_got), (dtype, n_ref, n_got, n_match)
-    return n_ref, n_got, n_match, float(sc_err)
+    s = yo.parity_summary(ref, got, tol, dec_ref, dec)
+    assert s["n_ref"] >= min_dets, s
+    assert s["match_frac"] >= MATCH_16BIT[dtype], (dtype, s)
+    assert s["match_frac_iou_only"] >= 0.95, (dtype, s)
+    if dtype == "f16":
+        assert s["anchor_box_err_px_max"] <= tol, (dtype, s)                 # the same anchor's box, every anchor both sides report
+    else:
+        assert s["anchor_box_err_px_p50"] <= tol, (dtype, s)
+    return s
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_detect_16bit_modes_match_oracle_at_bench_config(dtype):
     """The speed modes end to end at BASELINE configs[1]: B=64, 640x640, YOLOv9-C."""
     frames = noise_frames(1, 64, 640, 640)
     sd, ref, feats, dec_ref = conditioned_case(frames)
     m = _yolo("c", 640, sd, dtype)
-    n_ref, n_got, n_match, sc_err = check_16bit_against_oracle(m, dtype, frames, ref, feats, dec_ref, min_dets=500)
-    print(f"{dtype}: {n_match}/{max(n_ref, n_got)} matched at IoU>=0.9, max score err {sc_err:.2e}")
+    s = check_16bit_against_oracle(m, dtype, frames, ref, feats, dec_ref, min_dets=500)
+    print(f"{dtype}: {s}")
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_detect_16bit_modes_with_unrounded_weights(dtype):
+    """The same network with its float32 weights NOT pre-rounded to 16-bit-exact values: the speed mode's own rounding of the
+    weights is inside the comparison.  Two references: (1) the storage-rounding emulation (what a correct 16-bit implementation
+    produces, f32 accumulation in another order): tight; (2) the f32 oracle: on this low-pass synthetic network weight rounding is
+    the dominant term (emulation: f16 97 % IoU matches, per-anchor p50 0.15 px; bf16 84 %, p50 1.0 px), the bars say so."""
+    frames = noise_frames(1, 16, 640, 640)
+    sd, ref, feats, dec_ref, emu = conditioned_case(frames, exact=False, emulate=(dtype,))
+    m = _yolo("c", 640, sd, dtype)
+    got = m.detect_batch(frames)
+    dec = m.get_tensor("decoded")
+    tol = 1e-3 * 640
+    vs_emu = yo.parity_summary(emu[dtype][0], got, tol, emu[dtype][1], dec)
+    vs_f32 = yo.parity_summary(ref, got, tol, dec_ref, dec)
+    print(f"{dtype} un-rounded weights: vs emulation {vs_emu}\n  vs f32 oracle {vs_f32}")
+    assert vs_emu["n_ref"] >= 100
+    if dtype == "f16":
+        assert vs_emu["match_frac"] >= 0.98 and vs_emu["anchor_box_err_px_p99"] <= tol, vs_emu
+        assert vs_f32["match_frac_iou_only"] >= 0.93 and vs_f32["anchor_box_err_px_p50"] <= tol, vs_f32
+    else:
+        assert vs_emu["match_frac_iou_only"] >= 0.93 and vs_emu["anchor_box_err_px_p50"] <= tol, vs_emu
+        assert vs_f32["match_frac_iou_only"] >= 0.70, vs_f32
 
 
 def test_conditioned_checkpoint_f32_mode():

@@ -81,7 +81,7 @@ def main():
         if hid not in seen or os.environ.get("CSP_DEBUG_ALL"):
             # with ONLY this block fused its input is the unfused network's, so every stage can be compared exactly
             seen.add(hid)
-            only = {"CLEARCAM_FUSE_CSP": level, "CLEARCAM_CSP_ONLY": str(k)}
+            only = {"CLEARCAM_DEV": "1", "CLEARCAM_FUSE_CSP": level, "CLEARCAM_CSP_ONLY": str(k)}
             st = {s: run(f"b{k}dbg{s}", dict(only, CLEARCAM_CSP_DBG=str(s)), args, tmp) for s in (1, 2, 3)}
             st[4] = run(f"b{k}full", only, args, tmp)
             ok &= report("stage 1 b   ", ab[..., hid:], st[1][f"csp{k}_u"][..., hid:])
