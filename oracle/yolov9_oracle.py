@@ -371,19 +371,25 @@ def match_detections(ref: np.ndarray, got: np.ndarray, iou_thr: float = 0.9):
     return len(r), len(g), n, box_err, sc_err
 
 
-def match_detections_strict(ref: np.ndarray, got: np.ndarray, box_tol: float, iou_thr: float = 0.9):
+def match_detections_strict(ref: np.ndarray, got: np.ndarray, box_tol: float, iou_thr: float = 0.9, score_margin: float = 0.0,
+                            conf: float = CONF_THRESHOLD):
     """The yardstick of the f32 gate applied pair by pair: a detection is matched only if a detection of the same class with
     IoU >= iou_thr exists on the other side AND its four coordinates lie within `box_tol` pixels (north_star's 1e-3 read as
     1e-3 * max(H, W)).  A pair that clears the IoU bar with a larger coordinate error is a different anchor that survived NMS
     among heavily overlapping candidates - a selection flip, counted as unmatched, not as a small error.
 
-    Returns a dict: n_ref, n_got, n_iou (pairs at IoU >= thr), n_strict (pairs also within box_tol), box_err (sorted array of
-    the coordinate errors of the IoU pairs), score_err_max (over strict pairs)."""
+    score_margin: an UNMATCHED detection whose own score lies within score_margin of the confidence threshold is reported as
+    `borderline`: the reference's `where(p >= 0.25, p, 0)` (detection/yolov9.py:446) is discontinuous there, and a score error
+    inside the mode's score tolerance legitimately makes such a row appear or disappear.
+
+    Returns a dict: n_ref, n_got, n_iou (pairs at IoU >= thr), n_strict (pairs also within box_tol), borderline_ref / borderline_got,
+    box_err (sorted array of the coordinate errors of the IoU pairs), score_err_max (over strict pairs)."""
     r = ref[ref[:, 4] > 0]
     g = got[got[:, 4] > 0]
     used = np.zeros(len(g), bool)
+    hit = np.zeros(len(r), bool)
     errs, n_strict, sc = [], 0, 0.0
-    for row in r:
+    for ri, row in enumerate(r):
         cand = np.nonzero(~used & (g[:, 5].astype(np.int64) == int(row[5])))[0]
         if not len(cand):
             continue
@@ -396,28 +402,35 @@ def match_detections_strict(ref: np.ndarray, got: np.ndarray, box_tol: float, io
         j = int(np.argmax(iou))
         if iou[j] >= iou_thr:
             used[cand[j]] = True
+            hit[ri] = True
             e = float(np.abs(row[:4] - c[j, :4]).max())
             errs.append(e)
             if e <= box_tol:
                 n_strict += 1
                 sc = max(sc, float(abs(row[4] - c[j, 4])))
     return {"n_ref": len(r), "n_got": len(g), "n_iou": len(errs), "n_strict": n_strict,
+            "borderline_ref": int((~hit & (r[:, 4] < conf + score_margin)).sum()), "borderline_got": int((~used & (g[:, 4] < conf + score_margin)).sum()),
             "box_err": np.sort(np.asarray(errs, np.float64)), "score_err_max": sc}
 
 
-def parity_summary(refs: np.ndarray, gots: np.ndarray, box_tol: float, dec_ref: np.ndarray = None, dec_got: np.ndarray = None) -> dict:
+def parity_summary(refs: np.ndarray, gots: np.ndarray, box_tol: float, dec_ref: np.ndarray = None, dec_got: np.ndarray = None,
+                   score_margin: float = 2e-3) -> dict:
     """match_detections_strict over a batch, plus (when the per-anchor decoded rows of both sides are given) the continuous
-    quantity behind it: coordinate error anchor by anchor over the anchors both sides score over the threshold."""
-    tot = {"n_ref": 0, "n_got": 0, "n_iou": 0, "n_strict": 0}
+    quantity behind it: coordinate error anchor by anchor over the anchors both sides score over the threshold.
+    match_frac = strict matches / max(n_ref, n_got); match_frac_clear_of_threshold leaves out of the denominator the unmatched
+    rows whose own score is within `score_margin` of the 0.25 threshold (see match_detections_strict)."""
+    tot = {"n_ref": 0, "n_got": 0, "n_iou": 0, "n_strict": 0, "borderline_ref": 0, "borderline_got": 0}
     errs, sc = [], 0.0
     for a, b in zip(refs, gots):
-        m = match_detections_strict(a, b, box_tol)
+        m = match_detections_strict(a, b, box_tol, score_margin=score_margin)
         for k in tot:
             tot[k] += m[k]
         errs.append(m["box_err"]); sc = max(sc, m["score_err_max"])
     errs = np.sort(np.concatenate(errs)) if errs else np.zeros(0)
     den = max(tot["n_ref"], tot["n_got"], 1)
-    out = dict(tot, match_frac=tot["n_strict"] / den, match_frac_iou_only=tot["n_iou"] / den, box_tol_px=box_tol, score_err_max=sc,
+    den2 = max(tot["n_ref"] - tot["borderline_ref"], tot["n_got"] - tot["borderline_got"], 1)
+    out = dict(tot, match_frac=tot["n_strict"] / den, match_frac_clear_of_threshold=min(1.0, tot["n_strict"] / den2), score_margin=score_margin,
+               match_frac_iou_only=tot["n_iou"] / den, box_tol_px=box_tol, score_err_max=sc,
                box_err_px_p50=float(np.quantile(errs, 0.5)) if len(errs) else 0.0, box_err_px_p99=float(np.quantile(errs, 0.99)) if len(errs) else 0.0,
                box_err_px_max_strict=float(errs[errs <= box_tol].max()) if (errs <= box_tol).any() else 0.0,
                box_err_px_max_iou_pairs=float(errs.max()) if len(errs) else 0.0)
