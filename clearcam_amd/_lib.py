@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libclearcam_hip.so")
 SYMBOLS = [
     "cc_last_error", "cc_version", "cc_device_count",
     "cc_yolo_create", "cc_yolo_load", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_get_tensor",
-    "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_profile_graph", "cc_yolo_destroy", "cc_conv2d_nhwc", "cc_conv_bench",
+    "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_profile_graph", "cc_yolo_destroy", "cc_conv2d_nhwc", "cc_conv_bench", "cc_dev_set",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
     "cc_clip_last_gpu_ms", "cc_clip_destroy", "cc_crop_preprocess", "cc_cv_resize_linear_u8", "cc_cv_warp_affine_u8",
     "cc_blaze_create", "cc_blaze_load", "cc_blaze_finalize", "cc_blaze_detect", "cc_blaze_destroy",
@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
         "cc_conv2d_nhwc": [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, vp, C.c_int, vp],
         "cc_conv_bench": [C.c_int] * 11 + [fp],
+        "cc_dev_set": [C.c_char_p, C.c_int],
         "cc_clip_create": [C.POINTER(vp), C.POINTER(ClipConfig), C.c_int, C.c_int],
         "cc_clip_load": [vp, C.c_char_p, vp, i64p, C.c_int],
         "cc_clip_finalize": [vp],

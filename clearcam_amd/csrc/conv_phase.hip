@@ -292,190 +292,12 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   conv_epilogue<T, BM, BN, 2, MI, NJ, NT, true>(p, acc, n0, lds, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; });
 }
 
-// ---- the same kernel as a PERSISTENT loop over tiles (one block per CU) ------------------------------------------------------
-// A 256x256 tile costs ~11 us outside its K loop (block dispatch, loader set-up + the latency of the first DMA pieces, the
-// activation epilogue, the staged store): a third of the time of a K = 1024 GEMM tile and most of a K = 256 one.  Here a block
-// walks tiles b, b + grid, ...; when a tile's K loop ends it sets up the NEXT tile's loader and issues its first twelve DMA
-// pieces, and only then runs the epilogue - straight from registers (8-byte / 16-byte stores, no LDS, no barrier), so the LDS
-// stages already belong to the next tile.  Dispatch gaps and the first-DMA latency disappear behind the epilogue VALU work.
-// Schedule 1 of conv_phase_kernel inside; same results bit for bit.
-// MEASURED (MI355X, bf16, r02): SLOWER than one tile per block on every shape tried - CLIP fc GEMM 736 vs 632 us, head 3x3 554 vs
-// 510 us, 1x1 256->256 @160x160 666 vs 512 us.  The register epilogue stores 32-byte row segments (a 16x16 MFMA tile is 16
-// channels wide) where the LDS-staged one writes whole 512-byte rows, and that costs more than dispatch + first-DMA latency
-// saved.  Kept behind CLEARCAM_PHASE_FLAGS=256 for the record and as the base of a staged-epilogue variant; not the default.
-template <class T>
-__global__ __launch_bounds__(512) void conv_phase_persist_kernel(const ConvP p, const ConvAux a) {
-  constexpr int BM = 256, BN = 256, NT = 512, MI = 8, NJ = 4;
-  constexpr int E = 8, CPRW = 8, BK = 64, RPP = NT / CPRW, XR = BM / RPP;
-  constexpr int STAGE = (BM + BN) * CPRW;
-  constexpr unsigned SB = STAGE * 16u;
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = wave >> 2, wq = wave & 3;
-  const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
-  const unsigned lds_base = lds_addr(lds);
-  const int ntiles = a.ntiles;
-  const int ppos = tid % CPRW, prow = tid / CPRW;
-  const int chunk = ppos ^ swz<CPRW>(prow);
-  struct RowInfo { const char* ptr; unsigned long long aux; };
-  RowInfo* rinfo = reinterpret_cast<RowInfo*>(lds + 2 * STAGE) + tid * XR;
-  const char* cur[XR]; unsigned inc[XR];
-  const char* wptr = nullptr;
-  const size_t wpass = (size_t)RPP * p.Kw * sizeof(T);
-  int kc = 0, tap = 0, pt = 0, wt = 0, m0 = 0, n0 = 0;
-  const int nkt = (p.Ktot + BK - 1) / BK;
-
-  auto retarget = [&]() {
-    const int kr = a.two ? 0 : tap / p.ks, ks_ = a.two ? 0 : tap - kr * p.ks;
-    const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc + chunk * E) * (long)sizeof(T);
-#pragma unroll
-    for (int i = 0; i < XR; ++i) {
-      const RowInfo ri = rinfo[i];
-      const bool ok = a.two ? ri.ptr != nullptr : (bool)((ri.aux >> tap) & 1u);
-      const char* src = (a.two && tap) ? reinterpret_cast<const char*>(ri.aux) : ri.ptr;
-      cur[i] = ok ? src + delta : reinterpret_cast<const char*>(&g_zero16);
-      inc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
-    }
-  };
-  auto setup_tile = [&](int vb) {                      // loader state of tile `vb` (XCD-aware order as in the one-tile kernel)
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7, idx = vb >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int mt_ = wg / a.nt;
-    m0 = mt_ * BM; n0 = (wg - mt_ * a.nt) * BN;
-#pragma unroll
-    for (int i = 0; i < XR; ++i) {
-      const int m = m0 + prow + RPP * i;
-      RowInfo ri;
-      if (a.two) {
-        const int mm = m < M ? m : 0;
-        const int b = fdiv(mm, hw, a.inv_hw), rem = mm - b * hw, ho = fdiv(rem, p.Wo, a.inv_wo), wo = rem - ho * p.Wo;
-        const long i0 = ((long)b * p.s0.H + (ho >> p.s0.shift)) * p.s0.W + (wo >> p.s0.shift);
-        const long i1 = ((long)b * p.s1.H + (ho >> p.s1.shift)) * p.s1.W + (wo >> p.s1.shift);
-        ri.ptr = m < M ? reinterpret_cast<const char*>(p.s0.ptr) + (i0 * p.s0.cstride + p.s0.coff) * (long)sizeof(T) : nullptr;
-        ri.aux = (unsigned long long)(reinterpret_cast<const char*>(p.s1.ptr) + (i1 * p.s1.cstride + p.s1.coff) * (long)sizeof(T));
-      } else if (a.is1x1) {
-        ri.ptr = reinterpret_cast<const char*>(p.s0.ptr) + ((size_t)m * p.s0.cstride + p.s0.coff) * sizeof(T);
-        ri.aux = m < M ? 1u : 0u;
-      } else {
-        const int mm = m < M ? m : 0;
-        const int b = fdiv(mm, hw, a.inv_hw), rem = mm - b * hw, ho = fdiv(rem, p.Wo, a.inv_wo), wo = rem - ho * p.Wo;
-        const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
-        unsigned hm = 0, wmk = 0;
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-          hm |= (unsigned)(rr < p.ks && (unsigned)(h0 + rr) < (unsigned)p.Hin) << rr;
-          wmk |= (unsigned)(rr < p.ks && (unsigned)(w0 + rr) < (unsigned)p.Win) << rr;
-        }
-        const unsigned vm = ((hm & 1u) ? wmk : 0u) | ((hm & 2u) ? wmk << p.ks : 0u) | ((hm & 4u) ? wmk << (2 * p.ks) : 0u);
-        ri.aux = m < M ? vm : 0u;
-        ri.ptr = reinterpret_cast<const char*>(p.s0.ptr) +
-                 ((((long)b * p.s0.H + h0) * p.s0.W + w0) * (long)p.s0.cstride + p.s0.coff) * (long)sizeof(T);
-      }
-      rinfo[i] = ri;
-    }
-    wptr = reinterpret_cast<const char*>(p.w) + ((size_t)(n0 + prow) * p.Kw + chunk * E) * sizeof(T);
-    kc = 0; tap = 0; pt = 0; wt = 0;
-    retarget();
-  };
-  auto advance_p = [&]() {
-    kc += BK;
-    if (kc == (a.two ? (tap ? p.s1.C : p.s0.C) : p.Cin)) { kc = 0; ++tap; retarget(); }
-    else {
-#pragma unroll
-      for (int i = 0; i < XR; ++i) cur[i] += inc[i];
-    }
-  };
-  const unsigned wave_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * 64) * 16u);
-  auto issue_p = [&](unsigned stage_bytes, int h) {
-    const unsigned sb = wave_lds + stage_bytes;
-    glds16_m0(cur[2 * h], sb + (2 * h) * (NT * 16u)); glds16_m0(cur[2 * h + 1], sb + (2 * h + 1) * (NT * 16u));
-  };
-  auto issue_w = [&](unsigned stage_bytes, int h) {
-    const unsigned sb = wave_lds + stage_bytes + (unsigned)(BM * CPRW) * 16u;
-    glds16_m0(wptr + (2 * h) * wpass, sb + (2 * h) * (NT * 16u)); glds16_m0(wptr + (2 * h + 1) * wpass, sb + (2 * h + 1) * (NT * 16u));
-  };
-  auto step_w = [&]() { if (wt + 1 < nkt) { wptr += BK * sizeof(T); ++wt; } };
-  auto step_p = [&]() { if (pt + 1 < nkt) { advance_p(); ++pt; } };
-  auto first_pieces = [&]() {                          // tile 0 of the K walk complete, the weights of tile 1 on their way
-    issue_p(0, 0); issue_p(0, 1); step_p();
-    issue_w(0, 0); issue_w(0, 1); step_w();
-    issue_w(SB, 0); issue_w(SB, 1); step_w();
-  };
-
-  const int fr = lane & 15, fg = lane >> 4;
-  const int sw = (fr >> 1) & 7;
-  const char* ldsb = reinterpret_cast<const char*>(lds);
-  const char* pb[2] = {ldsb + (grp * 128 + fr) * 128 + ((fg ^ sw) * 16), ldsb + (grp * 128 + fr) * 128 + (((4 + fg) ^ sw) * 16)};
-  const char* wbp[2] = {ldsb + (BM + wq * 64 + fr) * 128 + ((fg ^ sw) * 16), ldsb + (BM + wq * 64 + fr) * 128 + (((4 + fg) ^ sw) * 16)};
-  uint4 pa[8], wb[4], wb1[4];
-  f32x4 acc[NJ][MI];
-  auto read_p = [&](unsigned so, int ps) {
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pa[kh * 4 + i] = *reinterpret_cast<const uint4*>(pb[kh] + so + (ps * 64 + i * 16) * 128);
-  };
-  auto read_w = [&](unsigned so, int ws, uint4 (&dst)[4]) {
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) dst[kh * 2 + j] = *reinterpret_cast<const uint4*>(wbp[kh] + so + (ws * 32 + j * 16) * 128);
-  };
-  auto mma_w = [&](int ps, int ws, const uint4 (&wv)[4]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Mma<T>::run(wv[kh * 2 + j], pa[kh * 4 + i], acc[ws * 2 + j][ps * 4 + i]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto sync = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
-
-  int vb = blockIdx.x;
-  setup_tile(vb);
-  first_pieces();
-  for (; vb < ntiles; vb += gridDim.x) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wait_vmcnt<0>();                                   // the first pieces of this tile (and the previous tile's stores) are done
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0 through the K loop
-    __builtin_amdgcn_sched_barrier(0);
-    for (int t = 0; t < nkt; ++t) {
-      const unsigned so = (t & 1) ? SB : 0u, no = SB - so;
-      read_w(so, 0, wb); read_p(so, 0);
-      issue_p(no, 0);
-      sync(); mma_w(0, 0, wb); sync();
-      read_w(so, 1, wb1);
-      issue_p(no, 1); step_p();
-      sync(); mma_w(0, 1, wb1); sync();
-      read_p(so, 1);
-      sync(); mma_w(1, 1, wb1); sync();
-      issue_w(so, 0); issue_w(so, 1); step_w();
-      wait_vmcnt<4>();
-      sync(); mma_w(1, 0, wb); sync();
-    }
-    wait_vmcnt<0>();                                   // this wave's surplus pieces have landed: its stage slices are free
-    if (grp == 0) __builtin_amdgcn_s_barrier();        // everybody is out of the K loop
-    __builtin_amdgcn_sched_barrier(0);
-    const int em0 = m0, en0 = n0;
-    if (vb + (int)gridDim.x < ntiles) { setup_tile(vb + gridDim.x); first_pieces(); }   // next tile's DMA runs under the epilogue
-    __builtin_amdgcn_sched_barrier(0);
-    long mrow[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) { const int m = em0 + grp * 128 + i * 16 + fr; mrow[i] = m < M ? (long)m : -1L; }
-    const int nb = en0 + wq * 64 + fg * 4;
-    if (p.act == 1) direct_tile<T, 1, MI, NJ>(p, acc, mrow, nb);
-    else if (p.act == 2) direct_tile<T, 2, MI, NJ>(p, acc, mrow, nb);
-    else if (p.act == 3) direct_tile<T, 3, MI, NJ>(p, acc, mrow, nb);
-    else if (p.act == 4) direct_tile<T, 4, MI, NJ>(p, acc, mrow, nb);
-    else direct_tile<T, 0, MI, NJ>(p, acc, mrow, nb);
-  }
-}
+// The persistent-loop form of this kernel (next tile's first DMA pieces under a wave-private LDS-staged epilogue) is in
+// conv_persist.hip.  The r02 persistent form with a REGISTER epilogue (32-byte store segments) measured slower than one tile per
+// block on every shape (CLIP fc GEMM 736 vs 632 us) and was removed.
+bool conv_persist_ok(const ConvP& p);
+void launch_conv_persist(int dt, int mm, int abl, const ConvP& p, const ConvAux& a, int M, hipStream_t stream);
+int g_phase_flags_override = -1;                       // cc_dev_set("phase_flags", v): A/B inside one process (tools/dev)
 
 template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * 512 * 8 * 16 + 512 * 4 * 16;     // two K tiles of (256 + 256) rows x 128 bytes + the per-row loader table
@@ -486,24 +308,25 @@ template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, in
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
-  static int flags = -1;
-  if (flags < 0) { const char* e = getenv("CLEARCAM_PHASE_FLAGS"); flags = e ? atoi(e) : 32; }   // 32: schedule 1 (default); 0: schedule 0; 8 / 16: timing ablations of schedule 0
+  static int env_flags = -2;
+  // CLEARCAM_PHASE_FLAGS: unset = the default rule below; 32: schedule 1 one tile per block; 0: schedule 0; 8 / 16: timing ablations of
+  // schedule 0; 64: buffer-descriptor DMA; 512: persistent loop with the wave-staged epilogue (conv_persist.hip) for every
+  // eligible layer, + 1024: on v_mfma_f32_32x32x16, + 2048: drain the previous tile's stores before the next K loop, bits 12-15:
+  // its timing ablations (development)
+  if (env_flags == -2) { const char* e = getenv("CLEARCAM_PHASE_FLAGS"); env_flags = e ? atoi(e) : -1; }
+  int flags = g_phase_flags_override >= 0 ? g_phase_flags_override : env_flags;
+  if (flags < 0) {
+    // Default: the persistent loop where a block walks at least ~2.5 tiles (same results bit for bit; r03 A/B on MI355X: CLIP GEMMs
+    // +3-6 %, 1x1 convs at 80x80 / 160x160 +4-10 %, 3x3 256->256 at 80x80 +-1 %), one tile per block below that (400-tile layers at
+    // 40x40: the persistent form measured 2-4 % slower - its second round is as ragged, and the first has no dispatch skew)
+    const long tiles = (long)((M + 255) / 256) * a.nt;
+    flags = (tiles >= 640 && conv_persist_ok(p)) ? 512 : 32;
+  }
   ConvAux b = a; b.flags = flags;
   const size_t xb = (size_t)p.B * p.s0.H * p.s0.W * p.s0.cstride * sizeof(T), wbytes = (size_t)p.Cout * p.Kw * sizeof(T);
   const bool buf_ok = xb < ((size_t)1 << 32) - 256 && wbytes < ((size_t)1 << 32) - 256;
   b.x_bytes = (unsigned)xb; b.w_bytes = (unsigned)wbytes;
-  if (flags & 256) {
-    static int cus = 0;
-    if (!cus) {
-      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_persist_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      int dev = 0; hipDeviceProp_t pr;
-      CC_HIP(hipGetDevice(&dev)); CC_HIP(hipGetDeviceProperties(&pr, dev));
-      cus = pr.multiProcessorCount;
-    }
-    b.ntiles = ((M + 255) / 256) * a.nt;
-    hipLaunchKernelGGL((conv_phase_persist_kernel<T>), dim3(std::min(b.ntiles, cus)), dim3(512), lds, stream, p, b);
-    return;
-  }
+  if ((flags & 512) && conv_persist_ok(p)) { launch_conv_persist(TypeTag<T>::dt, (flags & 1024) ? 1 : 0, (flags >> 12) & 15, p, b, M, stream); return; }
   if ((flags & 64) && buf_ok && !a.two) { hipLaunchKernelGGL((conv_phase_kernel<T, 2>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b); return; }
   if (flags & 32) hipLaunchKernelGGL((conv_phase_kernel<T, 1>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
   else hipLaunchKernelGGL((conv_phase_kernel<T, 0>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);

@@ -685,6 +685,8 @@ namespace cc { void set_error(const std::string& m) { g_err = m; } }
   catch (const cc::Error& e) { cc::set_error(e.what()); return e.code; }   \
   catch (const std::exception& e) { cc::set_error(e.what()); return -1; }
 
+namespace cc { extern int g_phase_flags_override; }   // conv_phase.hip
+
 extern "C" {
 
 const char* cc_last_error(void) { return g_err.c_str(); }
@@ -986,6 +988,14 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
   if (force_direct == 1) launch_conv_direct(dtype, c, (hipStream_t)stream); else launch_conv(dtype, c, (hipStream_t)stream);
   CC_HIP(hipStreamSynchronize((hipStream_t)stream));
   hipFree(pc.w); hipFree(pc.bias);
+  CC_API_END
+}
+
+int cc_dev_set(const char* key, int value) {
+  CC_API_BEGIN
+  CC_CHECK(key, "null key");
+  if (std::string(key) == "phase_flags") cc::g_phase_flags_override = value;
+  else throw cc::Error(-22, std::string("cc_dev_set: unknown key ") + key);
   CC_API_END
 }
 

@@ -80,6 +80,10 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
 /* Diagnostic (kernel tuning, tools/dev/phase_ab.py): average device milliseconds of one launch of the conv above on random
  * 16-bit data resident in HBM, weights packed once, `iters` launches between two events.  Not part of the drop-in surface. */
 int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int variant, int iters, float* ms);
+/* Diagnostic (kernel tuning): set a process-wide tuning switch at run time so that one process can A/B kernel variants.
+ * key "phase_flags": the CLEARCAM_PHASE_FLAGS bit set of the eight-wave kernel (-1 = back to the environment / default).
+ * Plans already built keep the launches they were built with.  Not part of the drop-in surface. */
+int cc_dev_set(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * CLIP — stands behind `OpenCLIP.precompute_embedding(x)` (models/objects.py:94-133) and

@@ -487,6 +487,40 @@ def test_big_tile_kernel_matches_torch(case, dtype, variant):
     assert float((got - ref).abs().max() / ref.abs().max()) <= TOL[dtype]
 
 
+PERSIST_CASES = BIG_CASES + [
+    ("persist_many_tiles", 40, 256, 48, 48, 512, 1),     # 360 x 2 = 720 tiles on 256 blocks: every block walks 2-3 tiles (next tile's DMA under the epilogue)
+    ("persist_3x3_many", 24, 64, 40, 40, 256, 3),        # 150 tiles... one round, 9 K steps of one tap each (retarget every step)
+    ("persist_k64_many", 64, 64, 32, 32, 256, 1),        # single K step per tile, 256 tiles
+]
+
+
+@pytest.mark.parametrize("mm", [0, 1], ids=["mfma16x16x32", "mfma32x32x16"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", PERSIST_CASES, ids=[c[0] for c in PERSIST_CASES])
+def test_persistent_eight_wave_kernel_matches_torch(case, dtype, mm):
+    """conv_persist_kernel (persistent tile loop, wave-private LDS-staged epilogue; conv_persist.hip) on both matrix-instruction
+    shapes, selected at run time through cc_dev_set("phase_flags", ...), against torch; SiLU and no activation."""
+    from clearcam_amd import _lib as lib_
+    L = lib_.lib()
+    _, B, Cin, H, W_, Cout, k = case
+    g = torch.Generator().manual_seed(hash(case[0]) % 1000)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    lin = F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b, padding=k // 2)
+    try:
+        lib_.check(L.cc_dev_set(b"phase_flags", 512 + (1024 if mm else 0)))
+        for act, ref in ((1, F.silu(lin)), (0, lin)):
+            got = conv_hip(x, w, b, 1, 1, act, dtype, force_direct=7)
+            assert float((got - ref).abs().max() / ref.abs().max()) <= TOL[dtype], (case[0], act)
+        again = conv_hip(x, w, b, 1, 1, 0, dtype, force_direct=7)
+        assert torch.equal(again, got)                                      # deterministic (no race between a tile's epilogue and the next tile's DMA)
+    finally:
+        lib_.check(L.cc_dev_set(b"phase_flags", -1))
+    if mm == 0:                                                             # same accumulation grouping as the one-tile-per-block kernel: same bits
+        assert torch.equal(conv_hip(x, w, b, 1, 1, 0, dtype, force_direct=7), got)
+
+
 _STEM_SCRIPT = r"""
 import sys, numpy as np
 from clearcam_amd.weights import synthetic_yolov9_state_dict
