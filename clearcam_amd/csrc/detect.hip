@@ -327,6 +327,31 @@ void launch_preprocess(int dt, const PreP& p, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// decode arithmetic, shared by decode_kernel and the fused head_tail_kernel (one definition: the same f32 operations in the same
+// order, so the two paths produce the same bits)
+// DFL (detection/yolov9.py:273-282): softmax over the 16 bins of one box side, then the 1x1 conv with the loaded 16 weights
+__device__ __forceinline__ float dfl_expect(float (&v)[16], const float (&w16)[16]) {
+  float mx = v[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - mx); s += v[i]; }
+  float e = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) e = __fadd_rn(e, __fmul_rn(__fdiv_rn(v[i], s), w16[i]));
+  return e;
+}
+// dist2bbox(xywh) * stride -> xyxy (:263-271, :440-441) for anchor cell (a % W, a / W)
+__device__ __forceinline__ void dist_to_box(const float (&d)[4], int a, int W, float stride, float (&o)[4]) {
+  const float ax = (float)(a % W) + 0.5f, ay = (float)(a / W) + 0.5f;
+  const float lx = ax - d[0], ly = ay - d[1], rx = ax + d[2], ry = ay + d[3];
+  const float cx = ((lx + rx) / 2.f) * stride, cy = ((ly + ry) / 2.f) * stride;
+  const float bw = (rx - lx) * stride, bh = (ry - ly) * stride;
+  o[0] = cx - bw / 2.f; o[1] = cy - bh / 2.f; o[2] = cx + bw / 2.f; o[3] = cy + bh / 2.f;
+}
+__device__ __forceinline__ float class_sigmoid(float l) { return 1.0f / (1.0f + expf(-l)); }
+
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)p.B * p.A) return;
@@ -346,21 +371,10 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
     float v[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const float4 t = r[side * 4 + q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
-    float mx = v[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, v[i]);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - mx); s += v[i]; }
-    float e = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) e = __fadd_rn(e, __fmul_rn(__fdiv_rn(v[i], s), w16[i]));
-    d[side] = e;
+    d[side] = dfl_expect(v, w16);
   }
-  const float ax = (float)(a % W) + 0.5f, ay = (float)(a / W) + 0.5f;
-  const float lx = ax - d[0], ly = ay - d[1], rx = ax + d[2], ry = ay + d[3];
-  const float cx = ((lx + rx) / 2.f) * stride, cy = ((ly + ry) / 2.f) * stride;
-  const float bw = (rx - lx) * stride, bh = (ry - ly) * stride;
+  float box[4];
+  dist_to_box(d, a, W, stride, box);
   float best = -1.f; int bi = 0;
 #pragma unroll 4
   for (int q = 0; q < 20; ++q) {
@@ -368,14 +382,142 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
     const float l[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float sg = 1.0f / (1.0f + expf(-l[e]));
+      const float sg = class_sigmoid(l[e]);
       if (sg > best) { best = sg; bi = q * 4 + e; }
     }
   }
   float* o = p.det + idx * 6;
-  o[0] = cx - bw / 2.f; o[1] = cy - bh / 2.f; o[2] = cx + bw / 2.f; o[3] = cy + bh / 2.f;
+  o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3];
   o[4] = best >= p.conf ? best : 0.f;
   o[5] = (float)bi;
+}
+
+// ---- DDetect tail: last 1x1 convs of both branches + decode, logits on chip ---------------------------------------------------
+// One block = four waves; a wave owns 16 pixels at a time (one MFMA pixel fragment) and walks TPB tiles of 64 pixels with the
+// block.  Weights of the level (box 64 x 64, class 80 x CH) sit in LDS for the block's lifetime (rows padded by 16 bytes: fragment
+// reads spread over the banks); pixel fragments come straight from global memory into registers (each is used by one wave only).
+//   box branch:   4 channel fragments x K 64      class branch: 5 channel fragments x K CH     (ascending K, one accumulator each:
+//   the accumulation order of every conv kernel in this library, so the logits equal the two conv launches' bit for bit)
+//   class scores: sigmoid + running (max, argmax) over the lane's 20 logits in registers, then over the four lanes that share a
+//                 pixel (ties -> lower class index = decode_kernel's first-maximum scan)
+//   box:          the 64 box logits of a pixel go through LDS so that lane (pixel, side) runs decode_kernel's own 16-bin sequence
+constexpr int kTailTPB = 8;            // 64-pixel tiles per block
+template <class T, int CH>
+__global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int blk1, int blk2) {
+  constexpr int KC3 = CH / 32, ROW3 = CH * 2 + 16, ROW2 = 64 * 2 + 16, LROW = 68;      // LDS row strides: bytes, bytes, floats
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* w3s = smem;                                    // 80 rows x ROW3
+  char* w2s = smem + 80 * ROW3;                        // 64 rows x ROW2
+  float* lg = reinterpret_cast<float*>(smem + 80 * ROW3 + 64 * ROW2);   // [4 waves][16 pixels][LROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int lvl = (int)blockIdx.x >= blk2 ? 2 : ((int)blockIdx.x >= blk1 ? 1 : 0);
+  const int blk = (int)blockIdx.x - (lvl == 2 ? blk2 : (lvl == 1 ? blk1 : 0));
+  const int H = p.H[lvl], W = p.W[lvl], hw = H * W, M = p.B * hw;
+  const float stride = lvl == 0 ? 8.f : (lvl == 1 ? 16.f : 32.f);
+  int aoff = 0;
+  for (int l = 0; l < lvl; ++l) aoff += p.H[l] * p.W[l];
+  // weights -> LDS (16-byte chunks; rows are kw elements apart in global memory)
+  {
+    const char* g3 = reinterpret_cast<const char*>(p.w3[lvl]);
+    for (int c = tid; c < 80 * (CH / 8); c += 256) {
+      const int row = c / (CH / 8), ch = c - row * (CH / 8);
+      *reinterpret_cast<uint4*>(w3s + row * ROW3 + ch * 16) = *reinterpret_cast<const uint4*>(g3 + ((size_t)row * p.kw3 + ch * 8) * sizeof(T));
+    }
+    const char* g2 = reinterpret_cast<const char*>(p.w2[lvl]);
+    for (int c = tid; c < 64 * 8; c += 256) {
+      const int row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(w2s + row * ROW2 + ch * 16) = *reinterpret_cast<const uint4*>(g2 + ((size_t)row * p.kw2 + ch * 8) * sizeof(T));
+    }
+  }
+  float w16[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w16[i] = p.dfl_w[i];
+  float4 b2v[4], b3v[5];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b2v[j] = *reinterpret_cast<const float4*>(p.b2[lvl] + j * 16 + fg * 4);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) b3v[j] = *reinterpret_cast<const float4*>(p.b3[lvl] + j * 16 + fg * 4);
+  __syncthreads();
+  const T* bxp = reinterpret_cast<const T*>(p.bx[lvl]);
+  const T* clp = reinterpret_cast<const T*>(p.cl[lvl]);
+  float* lgw = lg + wave * 16 * LROW;
+  for (int t = 0; t < kTailTPB; ++t) {
+    const int m0 = (blk * kTailTPB + t) * 64 + wave * 16;
+    if (m0 >= M) break;                                // wave-uniform
+    const int m = m0 + fr, mc = m < M ? m : M - 1;     // ragged last fragment: clamped loads, guarded stores
+    uint4 xb[2], xc[KC3];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) xb[kc] = *reinterpret_cast<const uint4*>(bxp + (size_t)mc * 64 + (kc * 4 + fg) * 8);
+#pragma unroll
+    for (int kc = 0; kc < KC3; ++kc) xc[kc] = *reinterpret_cast<const uint4*>(clp + (size_t)mc * CH + (kc * 4 + fg) * 8);
+    // ---- box branch: logits -> LDS --------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) Mma<T>::run(*reinterpret_cast<const uint4*>(w2s + (j * 16 + fr) * ROW2 + (kc * 4 + fg) * 16), xb[kc], acc);
+      *reinterpret_cast<float4*>(lgw + fr * LROW + j * 16 + fg * 4) = make_float4(acc[0] + b2v[j].x, acc[1] + b2v[j].y, acc[2] + b2v[j].z, acc[3] + b2v[j].w);
+    }
+    // ---- class branch: sigmoid + max in registers ---------------------------------------------------------------------------
+    float best = -1.f; int bi = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < KC3; ++kc) Mma<T>::run(*reinterpret_cast<const uint4*>(w3s + (j * 16 + fr) * ROW3 + (kc * 4 + fg) * 16), xc[kc], acc);
+      const float l[4] = {acc[0] + b3v[j].x, acc[1] + b3v[j].y, acc[2] + b3v[j].z, acc[3] + b3v[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sg = class_sigmoid(l[e]);
+        if (sg > best) { best = sg; bi = j * 16 + fg * 4 + e; }
+      }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {          // lanes fr, fr+16, fr+32, fr+48 hold the same pixel
+      const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    // ---- DFL: lane (pixel fr, side fg) -----------------------------------------------------------------------------------
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's logits are in LDS (same-wave writes, in order)
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 tt = *reinterpret_cast<const float4*>(lgw + fr * LROW + fg * 16 + q * 4);
+      v[4 * q] = tt.x; v[4 * q + 1] = tt.y; v[4 * q + 2] = tt.z; v[4 * q + 3] = tt.w;
+    }
+    const float dme = dfl_expect(v, w16);
+    float d[4];
+#pragma unroll
+    for (int sd = 0; sd < 4; ++sd) d[sd] = __shfl(dme, fr + 16 * sd, 64);
+    const int b = m / hw, a = m - b * hw;
+    float box[4];
+    dist_to_box(d, a, W, stride, box);
+    if (m < M) {
+      float* o = p.det + ((size_t)b * p.A + aoff + a) * 6;
+      if (fg == 0) { o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3]; }
+      else if (fg == 1) { o[4] = best >= p.conf ? best : 0.f; o[5] = (float)bi; }
+    }
+    __builtin_amdgcn_wave_barrier();                    // the next tile overwrites this wave's logits
+  }
+}
+
+bool head_tail_supported(int dt, int ch) { return dt != F32 && (ch == 128 || ch == 256); }
+
+template <class T, int CH> static void launch_head_tail_t(const HeadTailP& p, hipStream_t stream) {
+  constexpr size_t lds = (size_t)80 * (CH * 2 + 16) + 64 * (64 * 2 + 16) + 4 * 16 * 68 * 4;
+  static bool configured = false;
+  if (!configured) { CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_tail_kernel<T, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = true; }
+  int nb[3];
+  for (int l = 0; l < 3; ++l) { const long M = (long)p.B * p.H[l] * p.W[l]; nb[l] = (int)((M + 64 * kTailTPB - 1) / (64 * kTailTPB)); }
+  hipLaunchKernelGGL((head_tail_kernel<T, CH>), dim3(nb[0] + nb[1] + nb[2]), dim3(256), lds, stream, p, nb[0], nb[0] + nb[1]);
+}
+
+void launch_head_tail(int dt, const HeadTailP& p, hipStream_t stream) {
+  CC_CHECK(head_tail_supported(dt, p.ch) && p.kw2 >= 64 && p.kw3 >= p.ch, "fused DDetect tail: unsupported dtype / class-branch width");
+  if (dt == F16) { if (p.ch == 256) launch_head_tail_t<f16_t, 256>(p, stream); else launch_head_tail_t<f16_t, 128>(p, stream); }
+  else { if (p.ch == 256) launch_head_tail_t<bf16_t, 256>(p, stream); else launch_head_tail_t<bf16_t, 128>(p, stream); }
+  CC_HIP(hipGetLastError());
 }
 
 void launch_decode(const DecodeP& p, hipStream_t stream) {

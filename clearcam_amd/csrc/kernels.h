@@ -95,6 +95,23 @@ struct DecodeP {              // DDetect decode + class max: detection/yolov9.py
 };
 void launch_decode(const DecodeP& p, hipStream_t stream);
 
+// DDetect's last 1x1 convs of both branches + decode in one launch (detection/yolov9.py:202-220,247-282): per level the box branch
+// cv2[l][2] (1x1, 64 -> 64, four groups densified) and the class branch cv3[l][2] (1x1, ch -> 80) over their 16-bit inputs, then DFL
+// softmax-expectation, dist2bbox, sigmoid, class max / argmax, threshold -> (B, A, 6) rows.  The 144 f32 logits per anchor stay on chip.
+// Same MFMA accumulation order as the conv kernels and decode_kernel's own arithmetic: bit-identical rows.
+struct HeadTailP {
+  const void* bx[3]; const void* cl[3];   // (B,H,W,64) and (B,H,W,ch) storage dtype, dense
+  const void* w2[3]; const void* w3[3];   // packed [64][kw2] / [80][kw3]
+  const float* b2[3]; const float* b3[3];
+  int H[3], W[3];
+  int kw2, kw3, ch;
+  int B, A;
+  const float* dfl_w; float conf;
+  float* det;                             // (B,A,6)
+};
+bool head_tail_supported(int dt, int ch);
+void launch_head_tail(int dt, const HeadTailP& p, hipStream_t stream);
+
 struct NmsP {                 // top-300 + mask NMS + scale_boxes: detection/yolov9.py:406-458
   const float* det; int B, A;
   float iou_thr;

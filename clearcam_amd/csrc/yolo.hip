@@ -45,8 +45,9 @@ struct View { int buf; int coff; int C; };
 struct In { View v; int shift; };
 
 struct Op {
-  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms, 4 fuse, 5 letterbox + first conv (launched before the graph: it reads the caller's frames), 6 fused RepNCSP
-  ConvP conv; PoolP pool; DecodeP dec; NmsP nms; FuseP fuse; StemP stem; CspP csp;
+  int kind;  // 0 conv, 1 pool, 2 decode, 3 nms, 4 fuse, 5 letterbox + first conv (launched before the graph: it reads the caller's frames), 6 fused RepNCSP,
+             // 7 fused DDetect tail (last 1x1 convs of both branches + decode)
+  ConvP conv; PoolP pool; DecodeP dec; NmsP nms; FuseP fuse; StemP stem; CspP csp; HeadTailP tail;
   double alg_macs = 0;   // algorithmic multiply-accumulates of this launch (no padding / densification)
 };
 
@@ -411,24 +412,49 @@ struct Builder {
     return whole(o);
   }
 
+  // DDetect's last 1x1 convs + decode as ONE launch (detect.hip head_tail_kernel): the (B,A,144) f32 logits never reach HBM.
+  // 16-bit storage, class-branch width a multiple of 32 up to 256 (sizes s, c, e); CLEARCAM_FUSE_HEAD=0 keeps the three launches per
+  // level + decode_kernel (and with them the "raw<l>" parity taps, which the f32 mode always has).
+  bool fuse_head_tail() const {
+    const char* e = getenv("CLEARCAM_FUSE_HEAD");
+    return (!e || atoi(e) != 0) && head_tail_supported(Y->dtype, a.cls_hidden);
+  }
   void head(const std::string& H22, const View (&feats)[3]) {
     Op dec{}; dec.kind = 2;
+    Op tail{}; tail.kind = 7;
+    const bool fused = fuse_head_tail();
     P->A = 0;
     for (int l = 0; l < 3; ++l) {
       const std::string hb = H22 + "cv2.list." + std::to_string(l) + ".list.", hc = H22 + "cv3.list." + std::to_string(l) + ".list.";
       const int H = P->bufs[feats[l].buf].H, W = P->bufs[feats[l].buf].W, ch = a.cls_hidden;
-      const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch), raw = new_buf(H, W, 144, true);
+      const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch);
       conv({{feats[l], 0}}, pconv({hb + "0.conv", hc + "0.conv"}, {1, 1}), whole(hbuf), 1, 1);
       conv({{slice(whole(hbuf), 0, 64), 0}}, pconv({hb + "1.conv"}, {4}), whole(bxb), 1, 1);
       conv({{slice(whole(hbuf), 64, ch), 0}}, pconv({hc + "1.conv"}, {1}), whole(clb), 1, 1);
-      conv({{whole(bxb), 0}}, pconv({hb + "2"}, {4}), slice(whole(raw), 0, 64), 1, 0);
-      conv({{whole(clb), 0}}, pconv({hc + "2"}, {1}), slice(whole(raw), 64, 80), 1, 0);
-      P->taps["raw" + std::to_string(l)] = raw;
-      dec.dec.raw[l] = (const float*)(intptr_t)raw; dec.dec.H[l] = H; dec.dec.W[l] = W;
+      const PackedConv &c2 = pconv({hb + "2"}, {4}), &c3 = pconv({hc + "2"}, {1});
+      if (fused) {
+        CC_CHECK(c2.cin == 64 && c2.cout == 64 && c2.k == 1 && c3.cin == ch && c3.cout == 80 && c3.k == 1, "fused DDetect tail: unexpected conv shapes");
+        HeadTailP& q = tail.tail;
+        q.bx[l] = (const void*)(intptr_t)bxb; q.cl[l] = (const void*)(intptr_t)clb;
+        q.w2[l] = c2.w; q.w3[l] = c3.w; q.b2[l] = c2.bias; q.b3[l] = c3.bias; q.kw2 = c2.kw; q.kw3 = c3.kw;
+        q.H[l] = H; q.W[l] = W;
+      } else {
+        const int raw = new_buf(H, W, 144, true);
+        conv({{whole(bxb), 0}}, c2, slice(whole(raw), 0, 64), 1, 0);
+        conv({{whole(clb), 0}}, c3, slice(whole(raw), 64, 80), 1, 0);
+        P->taps["raw" + std::to_string(l)] = raw;
+        dec.dec.raw[l] = (const float*)(intptr_t)raw; dec.dec.H[l] = H; dec.dec.W[l] = W;
+      }
       P->A += H * W;
     }
-    dec.dec.B = P->B; dec.dec.A = P->A; dec.dec.dfl_w = Y->dfl_w; dec.dec.conf = 0.25f;
-    P->ops.push_back(dec);
+    if (fused) {
+      HeadTailP& q = tail.tail;
+      q.B = P->B; q.A = P->A; q.ch = a.cls_hidden; q.dfl_w = Y->dfl_w; q.conf = 0.25f;
+      P->ops.push_back(tail);
+    } else {
+      dec.dec.B = P->B; dec.dec.A = P->A; dec.dec.dfl_w = Y->dfl_w; dec.dec.conf = 0.25f;
+      P->ops.push_back(dec);
+    }
     Op nms{}; nms.kind = 3;
     nms.nms.B = P->B; nms.nms.A = P->A; nms.nms.iou_thr = 0.45f;
     // scale_boxes (:406-416): python-float arithmetic, then f32 tensor ops
@@ -538,6 +564,7 @@ struct Builder {
       else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) touch(op.fuse.in[k], t); touch(op.fuse.out, t); }
       else if (op.kind == 5) touch(op.stem.out, -1);           // runs before the graph, whatever its position in the list
       else if (op.kind == 6) { touch(op.csp.x, t); touch(op.csp.out, t); }
+      else if (op.kind == 7) { for (int l = 0; l < 3; ++l) { touch(op.tail.bx[l], t); touch(op.tail.cl[l], t); } }
     }
     first[P->in_buf] = -1;                                     // written by the letterbox kernel before the first op
     for (auto& kv : P->taps) last[kv.second] = nops + 1;       // cc_yolo_get_tensor reads these after the run
@@ -587,6 +614,7 @@ struct Builder {
       else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) op.fuse.in[k] = ptr(op.fuse.in[k]); op.fuse.out = ptr(op.fuse.out); }
       else if (op.kind == 5) op.stem.out = ptr(op.stem.out);
       else if (op.kind == 6) { op.csp.x = ptr(op.csp.x); op.csp.out = ptr(op.csp.out); }
+      else if (op.kind == 7) { for (int l = 0; l < 3; ++l) { op.tail.bx[l] = ptr(op.tail.bx[l]); op.tail.cl[l] = ptr(op.tail.cl[l]); } op.tail.det = P->det; }
       else { op.nms.det = P->det; op.nms.out = P->out_dev; }
     }
   }
@@ -620,16 +648,24 @@ template <class T> static T* to_device(const std::vector<T>& v) {
   return d;
 }
 
-static void run_ops(cc_yolo* Y, Plan* P, hipStream_t s) {
-  for (const Op& op : P->ops) {
-    if (op.kind == 0) launch_conv(Y->dtype, op.conv, s);
-    else if (op.kind == 1) launch_pool(Y->dtype, op.pool, s);
-    else if (op.kind == 2) launch_decode(op.dec, s);
-    else if (op.kind == 4) launch_fuse(Y->dtype, op.fuse, s);
-    else if (op.kind == 5) continue;                          // launched by run_stems, outside the graph
-    else if (op.kind == 6) launch_csp_fused(Y->dtype, op.csp, s);
-    else launch_topk_nms(op.nms, s);
+// One launch of the plan.  Kind 5 (fused letterbox + first conv) reads the caller's frames: inside the captured graph it is skipped
+// (run_stems launches it right before the graph); the profilers replay it on the frames of the last call.
+static void launch_op(int dtype, const Plan* P, const Op& op, hipStream_t s, bool with_stem) {
+  switch (op.kind) {
+    case 0: launch_conv(dtype, op.conv, s); break;
+    case 1: launch_pool(dtype, op.pool, s); break;
+    case 2: launch_decode(op.dec, s); break;
+    case 3: launch_topk_nms(op.nms, s); break;
+    case 4: launch_fuse(dtype, op.fuse, s); break;
+    case 5: if (with_stem) { StemP q = op.stem; q.pre.frames = P->last_frames; launch_stem_fused(dtype, q, s); } break;
+    case 6: launch_csp_fused(dtype, op.csp, s); break;
+    case 7: launch_head_tail(dtype, op.tail, s); break;
+    default: throw cc::Error(-22, "unknown op kind");
   }
+}
+
+static void run_ops(cc_yolo* Y, Plan* P, hipStream_t s) {
+  for (const Op& op : P->ops) launch_op(Y->dtype, P, op, s, false);
 }
 
 // The fused letterbox + first conv launches read the caller's frames, whose address changes from call to call, so they
@@ -768,12 +804,7 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
   if (getenv("CLEARCAM_EAGER_DEBUG")) {                      // development: launch by launch with a sync and a trace line after each
     int i = 0;
     for (const Op& op : P->ops) {
-      if (op.kind == 0) launch_conv(h->dtype, op.conv, s);
-      else if (op.kind == 1) launch_pool(h->dtype, op.pool, s);
-      else if (op.kind == 2) launch_decode(op.dec, s);
-      else if (op.kind == 4) launch_fuse(h->dtype, op.fuse, s);
-      else if (op.kind == 6) launch_csp_fused(h->dtype, op.csp, s);
-      else if (op.kind == 3) launch_topk_nms(op.nms, s);
+      launch_op(h->dtype, P, op, s, false);
       const hipError_t e = hipStreamSynchronize(s);
       fprintf(stderr, "[clearcam] op %d kind %d: %s\n", i, op.kind, hipGetErrorString(e)); fflush(stderr);
       ++i;
@@ -861,20 +892,16 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
     for (size_t i = 0; i < n; ++i) {
       const Op& op = P->ops[i];
       CC_HIP(hipEventRecord(ev[2 * i], s));
-      if (op.kind == 0) launch_conv(h->dtype, op.conv, s);
-      else if (op.kind == 1) launch_pool(h->dtype, op.pool, s);
-      else if (op.kind == 2) launch_decode(op.dec, s);
-      else if (op.kind == 4) launch_fuse(h->dtype, op.fuse, s);
-      else if (op.kind == 5) { StemP q = op.stem; q.pre.frames = P->last_frames; launch_stem_fused(h->dtype, q, s); }
-      else if (op.kind == 6) launch_csp_fused(h->dtype, op.csp, s);
-      else launch_topk_nms(op.nms, s);
+      launch_op(h->dtype, P, op, s, true);
       CC_HIP(hipEventRecord(ev[2 * i + 1], s));
     }
     CC_HIP(hipStreamSynchronize(s));
     for (size_t i = 0; i < n; ++i) {
       float t = 0; CC_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
       const int kd = P->ops[i].kind;
-      acc[kd == 4 ? 1 : (kd == 5 ? 4 : (kd == 6 ? 0 : kd))] += t;   // CBFuse counts with the pools; the fused letterbox + stem has its own slot; a fused RepNCSP is conv work
+      // CBFuse counts with the pools; the fused letterbox + stem has its own slot; a fused RepNCSP is conv work; the fused DDetect tail
+      // (last 1x1 convs + decode) is timed in the decode slot, its 0.35 % of the FLOPs stay out of the conv roofline
+      acc[kd == 4 ? 1 : (kd == 5 ? 4 : (kd == 6 ? 0 : (kd == 7 ? 2 : kd)))] += t;
     }
   }
   for (const Op& op : P->ops) if (op.kind == 0 || op.kind == 6) { macs += op.alg_macs; ++nconv; }
@@ -909,7 +936,7 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
           const double bytes = M * 4 * q.hid * es + (double)(8 + 18) * q.hid * q.hid * es;     // x in, out out, the four weight matrices
           fprintf(f, "%zu,csp_fused,%.4f,%.0f,%d,%d,3,1,%d,%.4f,%.1f,%.4f,%.0f\n", i, t, M, 2 * q.hid, (8 + 18) * q.hid, 2 * q.hid, op.alg_macs / 1e9,
                   2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9);
-        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : "topk_nms"), t);
+        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : (op.kind == 7 ? "head_tail" : "topk_nms")), t);
       }
       fclose(f);
     }
@@ -934,13 +961,7 @@ int cc_yolo_profile_graph(cc_yolo* h, int iters, int which, float* ms_per_replay
     for (const Op& op : P->ops) {
       const bool conv = op.kind == 0 || op.kind == 6;
       if (which == 0 ? !conv : (which == 1 ? conv : false)) continue;
-      if (op.kind == 0) launch_conv(h->dtype, op.conv, s);
-      else if (op.kind == 6) launch_csp_fused(h->dtype, op.csp, s);
-      else if (op.kind == 1) launch_pool(h->dtype, op.pool, s);
-      else if (op.kind == 2) launch_decode(op.dec, s);
-      else if (op.kind == 4) launch_fuse(h->dtype, op.fuse, s);
-      else if (op.kind == 5) { StemP q = op.stem; q.pre.frames = P->last_frames; launch_stem_fused(h->dtype, q, s); }
-      else launch_topk_nms(op.nms, s);
+      launch_op(h->dtype, P, op, s, true);
     }
   } catch (...) { hipStreamEndCapture(s, &graph); if (graph) hipGraphDestroy(graph); throw; }
   CC_HIP(hipStreamEndCapture(s, &graph));

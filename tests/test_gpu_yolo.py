@@ -623,6 +623,45 @@ def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fu
     assert np.abs(a["p3"]).max() > 0.05 and np.isfinite(a["p3"]).all()
 
 
+@pytest.mark.parametrize("size,res,dtype,shape", [
+    ("c", 640, "f16", (3, 640, 640, 3)),          # the bench network: class branch 256 wide; 3 frames: ragged 64-pixel tiles at 20x20
+    ("c", 640, "bf16", (2, 270, 480, 3)),         # letterboxed 384 x 640: non-square maps
+    ("s", 320, "f16", (5, 320, 320, 3)),          # class branch 128 wide
+    ("e", 640, "bf16", (1, 640, 640, 3)),         # the 43-block graph's head (model.list.42)
+])
+def test_fused_ddetect_tail_equals_unfused(size, res, dtype, shape):
+    """head_tail_kernel (DDetect's last 1x1 convs of both branches + DFL + dist2bbox + sigmoid + class max in one launch, the 144
+    logits per anchor never written) against the three launches per level + decode_kernel it replaces: same MFMA accumulation order,
+    decode_kernel's own arithmetic -> the decoded rows of every anchor and the detections are IDENTICAL, bit for bit."""
+    from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict
+    sd = conditioned_yolov9_state_dict("c", 1234) if size == "c" else synthetic_yolov9_state_dict(size, 1234)
+    frames = noise_frames(4, *shape[:3])
+    res_ = {}
+    for label, env in (("unfused", "0"), ("fused", "1")):
+        os.environ["CLEARCAM_FUSE_HEAD"] = env                                # read when the plan is built (first call of a shape)
+        try:
+            m = _yolo(size, res, sd, dtype)
+            det = m.detect_batch(frames)
+            dec = m.get_tensor("decoded")
+            os.environ["CLEARCAM_PROFILE_CSV"] = "/tmp/_tail_profile.csv"
+            prof = m.profile(iters=1)
+            has_raw = True
+            try:
+                m.get_tensor("raw0")
+            except Exception:                                                 # noqa: BLE001
+                has_raw = False
+            res_[label] = (det, dec, prof["conv_launches"], has_raw)
+            m.close()
+        finally:
+            os.environ.pop("CLEARCAM_FUSE_HEAD", None); os.environ.pop("CLEARCAM_PROFILE_CSV", None)
+    (d0, c0, n0, raw0), (d1, c1, n1, raw1) = res_["unfused"], res_["fused"]
+    assert raw0 and not raw1                                                  # the logits are not materialised any more
+    assert n0 - n1 == 6                                                       # two conv launches per level became part of the tail
+    assert np.array_equal(c0, c1)                                             # every anchor's decoded row
+    assert np.array_equal(d0, d1)
+    assert (c1[..., 4] > 0).sum() > 0 and np.isfinite(c1).all()
+
+
 _ADOWN_SCRIPT = r"""
 import csv, os, sys, numpy as np
 from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict
