@@ -9,7 +9,7 @@ from oracle import cv_warp_oracle as wo
 
 
 def test_cubic_resize_known_answers():
-    for case in (K.cubic_2x_impulse, K.cubic_2x_corner):
+    for case in (K.cubic_2x_impulse, K.cubic_2x_corner, K.cubic_4_to_5_impulse, K.cubic_4_to_5_flat_rows):
         src, size, exp = case()
         assert np.array_equal(ro.resize_cubic_u8(src, size[0]), exp), case.__name__
     # dyadic fractions: the four taps sum to exactly 2048, so a flat image stays flat under an exact 2x upscale
@@ -24,3 +24,13 @@ def test_linear_resize_known_answers():
 def test_warp_affine_known_answers():
     for src, M, dsize, exp in K.warp_cases():
         assert np.array_equal(wo.warp_affine_u8(src, M, dsize), exp), M.tolist()
+
+
+def test_tinygrad_uint8_interpolate_hand_worked_2x2_to_3x3():
+    """The detector's letterbox resize (tinygrad's uint8 `interpolate` with its 7-bit fixed-point lerp and int8 wrap) against a case
+    worked by hand from SURVEY.md Appendix B - a pin for the restatement in oracle/yolov9_oracle.py that is neither the
+    restatement itself nor the PyTorch stand-in the reference-run fixtures were generated over."""
+    from oracle import yolov9_oracle as yo
+    src, (w, h), exp = K.tinygrad_interpolate_u8_2x2_to_3x3()
+    got = yo.resize_bilinear(np.repeat(src[:, :, None], 3, 2), h, w)
+    assert np.array_equal(got, np.repeat(exp[:, :, None], 3, 2)), got[..., 0]

@@ -85,7 +85,7 @@ def test_kernels_reproduce_the_hand_computed_opencv_cases():
     import cv_kats as K
     from clearcam_amd import cvops
     from clearcam_amd.objects import preprocess_crops
-    for case in (K.cubic_2x_impulse, K.cubic_2x_corner):
+    for case in (K.cubic_2x_impulse, K.cubic_2x_corner, K.cubic_4_to_5_impulse, K.cubic_4_to_5_flat_rows):
         src, size, exp = case()
         got = preprocess_crops([src], size[0]).cpu().numpy()[0]                     # (3,8,8) float32 = (v/255 - 0.5)/0.5
         want = ((exp.astype(np.float32) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5)).transpose(2, 0, 1)
