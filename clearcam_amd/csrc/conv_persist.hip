@@ -557,8 +557,9 @@ template <class T, int MM, int ABL = 0> static void launch_persist_t(const ConvP
   hipLaunchKernelGGL((conv_persist_kernel<T, MM, ABL>), dim3(std::min(b.ntiles, cus)), dim3(512), lds, stream, p, b);
 }
 
-// abl: timing ablations (development; bf16, 16x16x32 only): index into {0, 1, 3, 4, 16, 11, 27, 32}; 8.. = {64, 96, 11 + 64}
+// abl: timing ablations (development build only: -DCC_PERSIST_ABLATIONS; bf16, 16x16x32; results are wrong with any of them)
 void launch_conv_persist(int dt, int mm, int abl, const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {
+#ifdef CC_PERSIST_ABLATIONS
   if (abl && dt == BF16 && !mm) {
     switch (abl) {
       case 1: launch_persist_t<bf16_t, 0, 1>(p, a, M, stream); return;    // no DMA in the loop
@@ -574,6 +575,8 @@ void launch_conv_persist(int dt, int mm, int abl, const ConvP& p, const ConvAux&
       default: break;
     }
   }
+#endif
+  (void)abl;
   if (dt == F16) { if (mm) launch_persist_t<f16_t, 1>(p, a, M, stream); else launch_persist_t<f16_t, 0>(p, a, M, stream); }
   else { if (mm) launch_persist_t<bf16_t, 1>(p, a, M, stream); else launch_persist_t<bf16_t, 0>(p, a, M, stream); }
 }

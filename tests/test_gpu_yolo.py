@@ -491,6 +491,9 @@ PERSIST_CASES = BIG_CASES + [
     ("persist_many_tiles", 40, 256, 48, 48, 512, 1),     # 360 x 2 = 720 tiles on 256 blocks: every block walks 2-3 tiles (next tile's DMA under the epilogue)
     ("persist_3x3_many", 24, 64, 40, 40, 256, 3),        # 150 tiles... one round, 9 K steps of one tap each (retarget every step)
     ("persist_k64_many", 64, 64, 32, 32, 256, 1),        # single K step per tile, 256 tiles
+    ("tiles_400", 25, 64, 64, 64, 256, 1),               # M = 102400 (the 40x40 maps of a 64-frame batch): 1.56 rounds of tiles
+    ("tiles_400_3x3", 25, 64, 64, 64, 256, 3),
+    ("tiles_800_two_channel_tiles", 25, 128, 64, 64, 512, 1),
 ]
 
 
@@ -518,7 +521,11 @@ def test_persistent_eight_wave_kernel_matches_torch(case, dtype, mm):
     finally:
         lib_.check(L.cc_dev_set(b"phase_flags", -1))
     if mm == 0:                                                             # same accumulation grouping as the one-tile-per-block kernel: same bits
-        assert torch.equal(conv_hip(x, w, b, 1, 1, 0, dtype, force_direct=7), got)
+        try:
+            lib_.check(L.cc_dev_set(b"phase_flags", 32))
+            assert torch.equal(conv_hip(x, w, b, 1, 1, 0, dtype, force_direct=7), got)
+        finally:
+            lib_.check(L.cc_dev_set(b"phase_flags", -1))
 
 
 _STEM_SCRIPT = r"""

@@ -1,7 +1,9 @@
 """dev tool: A/B of the eight-wave kernel's forms in ONE process (cc_dev_set("phase_flags", ...)):
     base     32          one 256x256 tile per block, schedule 1, block-wide LDS-staged epilogue (conv_phase_kernel)
-    persist  512         persistent tile loop, wave-private staged epilogue, v_mfma_f32_16x16x32 (conv_persist_kernel<T, 0>)
-    drain    512 + 2048  persist, but the previous tile's stores are drained (vmcnt(0)) before the next K loop
+    persist  512         persistent tile loop, wave-private staged epilogue (conv_persist_kernel<T, 0>)
+    Measured and removed (records under profiles/): + 2048 drain the previous tile's stores before the next K loop (no difference,
+    r03d); + 1024 v_mfma_f32_32x32x16 (10-15 % slower, r03b; still built, opt-in); block start stagger (no difference, r03f); the
+    last, partial round re-cut into shorter tiles (no gain: a 144-of-256-CU round already runs ~1.3x faster per tile, r03i)
     (p32     512 + 1024  persist on v_mfma_f32_32x32x16, conv_persist_kernel<T, 1>: measured 10-15 % slower, r03b)
 1. single layers through cc_conv_bench (random data, device time per launch), 2. the YOLOv9-C B=64 detect step, 3. CLIP ViT-L/14.
 
@@ -18,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from clearcam_amd import _lib  # noqa: E402
 
 L = _lib.lib()
-FORMS = [("base", 32), ("persist", 512), ("stag2", 512 + (2 << 16)), ("stag5", 512 + (5 << 16))]
+FORMS = [("base", 32), ("persist", 512)]
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 dtype = sys.argv[2] if len(sys.argv) > 2 else "f16"
 DT = {"f16": 1, "bf16": 2}[dtype]
@@ -38,6 +40,9 @@ SHAPES = [
     ("1x1 256->256 @160x160 B64", 64, 160, 160, 256, 256, 1, 1, 1),
     ("1x1 256->256 @80x80 B64", 64, 80, 80, 256, 256, 1, 1, 1),
     ("3x3 s2 256->256 @80->40 B64", 64, 80, 80, 256, 256, 3, 2, 1),
+    ("1x1 768->512 @40x40 B64", 64, 40, 40, 768, 512, 1, 1, 1),
+    ("1x1 512->512 @40x40 B64", 64, 40, 40, 512, 512, 1, 1, 1),
+    ("1x1 512->256 @80x80 B64", 64, 80, 80, 512, 256, 1, 1, 1),
 ]
 
 

@@ -1,5 +1,7 @@
 """dev tool: timing ablations of conv_persist_kernel (bf16, 16x16x32) through cc_conv_bench: where does a tile's time go?
-   python tools/dev/persist_ablate.py"""
+   python tools/dev/persist_ablate.py
+Needs a development build of the library: the ablation instantiations are compiled only with -DCC_PERSIST_ABLATIONS
+(HIPCC_EXTRA="-DCC_PERSIST_ABLATIONS" python -m clearcam_amd.build --force); without it every row times the full kernel."""
 import ctypes as C
 import os
 import sys
