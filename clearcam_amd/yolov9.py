@@ -25,7 +25,7 @@ MAX_DET = 300
 
 class YOLOv9:
     def __init__(self, size: str = "t", res: int = 1280, state_dict: Optional[Dict[str, np.ndarray]] = None,
-                 weights: Optional[str] = None, dtype: str = "bf16", device: int = 0):
+                 weights: Optional[str] = None, dtype: str = "f16", device: int = 0):
         if size not in YOLO_ARCH and size != "e":
             raise ValueError(f"unsupported size {size!r}: t, s, m, c, e")
         self.size, self.res, self.dtype, self.device = size, res, dtype, device

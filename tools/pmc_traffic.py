@@ -47,11 +47,13 @@ def main():
     fetch, fcalls = run_pass("FETCH_SIZE", base + "_f")
     write, wcalls = run_pass("WRITE_SIZE", base + "_w")
     replays = PASSES + 1
-    is_conv = lambda k: k.startswith("conv") or k.startswith("csp_fused")                                  # noqa: E731  every conv kernel family of conv_mfma.hip / conv_direct.hip / fused kernels
+    # every conv kernel family (conv_mfma / conv_phase / conv_persist / conv_direct / 3x3 specialisations / fused RepNCSP); rocprofv3
+    # leaves the _Float16 instantiations MANGLED (_ZN2cc19conv_persist_kernelIDF16_...), so match inside the name
+    is_conv = lambda k: (("conv" in k and "kernel" in k) or "csp_fused" in k) and "pool" not in k           # noqa: E731
     lines, conv_r, conv_w, pool_r, pool_w = [], 0.0, 0.0, 0.0, 0.0
     for k in sorted(set(fetch) | set(write)):
         r_b, w_b = 2.0 * fetch.get(k, 0.0) * 1024 / replays, write.get(k, 0.0) * 1024 / replays
-        if k.startswith("stem_fused"):
+        if "stem_fused" in k:
             r_b /= 2.0                                                         # dword loads of the uint8 frames: FETCH_SIZE taken as reported
         lines.append(f"{k[:100]:100} launches/step {fcalls.get(k, 0) / replays:7.1f}  read {r_b / 1e9:8.3f} GB  write {w_b / 1e9:8.3f} GB")
         if is_conv(k):
