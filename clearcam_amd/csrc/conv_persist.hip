@@ -462,24 +462,16 @@ __global__ __launch_bounds__(512) void conv_persist_kernel(const ConvP p, const 
     }
   };
 
-  // The previous tile's output stores need not be acknowledged before the next K loop starts - only the DMA pieces issued BEFORE
-  // them must have landed.  vmcnt retires vector-memory loads and stores in issue order on this target (hipcc's own counted
-  // waits rest on that), so when the epilogue issued exactly 16 store instructions per lane behind the twelve pieces (whole
-  // 256-pixel tile, 16-bit staged path: every store executes, EXEC is never empty), vmcnt(16) = "the pieces have landed".  A
-  // ragged tile (guarded stores may be skipped) and the f32 / residual path wait for everything.  Without this every CU drains
-  // its 128 KB of output at once, in step with all the others, with the matrix pipes idle (ablation: 5-9 us of a 35 us tile).
-  bool counted = false, counted32 = false;
+  // The loop top waits for EVERYTHING this wave has in flight (vmcnt(0)): the next tile's first pieces and the previous tile's
+  // stores.  Waiting for the pieces only (a counted vmcnt(16) behind exactly 16 store instructions, resting on vector-memory
+  // loads and stores retiring in issue order) was built and measured: no difference (profiles/r03d_persist_ab.txt) - the stall
+  // is at store ISSUE inside the epilogue, not at their acknowledgement - so the plain, obviously safe wait stays.
   int vb = blockIdx.x;
   setup_tile(vb);
   first_pieces();
   for (; vb < ntiles; vb += gridDim.x) {
     zero_acc();
-    // this tile's first pieces have landed (flag 2048: always drain everything, the r03 A/B).  f32 / residual path on a whole
-    // tile: 32 store instructions per lane were issued behind the pieces, so vmcnt(8) covers them as well
-    if (a.flags & 2048) wait_vmcnt<0>();
-    else if (counted) wait_vmcnt<16>();
-    else if (counted32) wait_vmcnt<8>();
-    else wait_vmcnt<0>();
+    wait_vmcnt<0>();                                   // this tile's first pieces have landed, the previous tile's stores are out
     __builtin_amdgcn_s_barrier();                      // ... for every wave; every wave's epilogue (its LDS rounds) is behind it
     if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0 through the K loop
     __builtin_amdgcn_sched_barrier(0);
@@ -510,8 +502,6 @@ __global__ __launch_bounds__(512) void conv_persist_kernel(const ConvP p, const 
     if (vb + (int)gridDim.x < ntiles) { setup_tile(vb + gridDim.x); if constexpr (!(ABL & 64)) first_pieces(); }   // next tile's DMA runs under the epilogue
     __builtin_amdgcn_sched_barrier(0);
     const bool full = em0 + BM <= M;
-    counted = full && staged16 && !(ABL & 16);
-    counted32 = full && !staged16 && !(ABL & 16);
     if constexpr (!(ABL & 16)) epilogue(em0, en0, bq, full);
     else {                                             // every accumulator stays live: the MFMAs must not become dead code
       if constexpr (MM == 0) {
@@ -575,10 +565,11 @@ void launch_conv_persist(int dt, int mm, int abl, const ConvP& p, const ConvAux&
       default: break;
     }
   }
+  // v_mfma_f32_32x32x16 (MM = 1): correct and bit-identical end to end, 10-15 % slower on every shape (profiles/r03b): development build only
+  if (mm) { if (dt == F16) launch_persist_t<f16_t, 1>(p, a, M, stream); else launch_persist_t<bf16_t, 1>(p, a, M, stream); return; }
 #endif
-  (void)abl;
-  if (dt == F16) { if (mm) launch_persist_t<f16_t, 1>(p, a, M, stream); else launch_persist_t<f16_t, 0>(p, a, M, stream); }
-  else { if (mm) launch_persist_t<bf16_t, 1>(p, a, M, stream); else launch_persist_t<bf16_t, 0>(p, a, M, stream); }
+  (void)abl; (void)mm;
+  if (dt == F16) launch_persist_t<f16_t, 0>(p, a, M, stream); else launch_persist_t<bf16_t, 0>(p, a, M, stream);
 }
 
 }  // namespace cc
