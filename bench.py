@@ -552,7 +552,7 @@ def main() -> None:
             pass
         alg_flops = 2.0 * prof["alg_macs_per_step"]
         parity = None
-        if on_gpu and not args.no_parity:
+        if on_gpu and world == 1 and not args.no_parity:      # N = 1 only, like the CPU baseline: the other ranks would wait at the final barrier
             try:
                 parity = measured_parity(local)
             except Exception as exc:             # noqa: BLE001  a side measurement must not take the headline down
