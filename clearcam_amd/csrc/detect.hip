@@ -441,15 +441,23 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int b
   const T* bxp = reinterpret_cast<const T*>(p.bx[lvl]);
   const T* clp = reinterpret_cast<const T*>(p.cl[lvl]);
   float* lgw = lg + wave * 16 * LROW;
-  for (int t = 0; t < kTailTPB; ++t) {
+  // pixel fragments of tile t+1 are requested before tile t is computed and decoded (the decode is ~4 k VALU cycles per tile, an
+  // HBM round trip about as long: without the prefetch every tile opened with a dependent load and nothing to do)
+  auto load_frags = [&](int t, uint4 (&xb)[2], uint4 (&xc)[KC3]) {
     const int m0 = (blk * kTailTPB + t) * 64 + wave * 16;
-    if (m0 >= M) break;                                // wave-uniform
-    const int m = m0 + fr, mc = m < M ? m : M - 1;     // ragged last fragment: clamped loads, guarded stores
-    uint4 xb[2], xc[KC3];
+    const int mc = min(m0 + fr, M - 1);                // past the last pixel (ragged fragment, or no tile t at all): clamped, never stored
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) xb[kc] = *reinterpret_cast<const uint4*>(bxp + (size_t)mc * 64 + (kc * 4 + fg) * 8);
 #pragma unroll
     for (int kc = 0; kc < KC3; ++kc) xc[kc] = *reinterpret_cast<const uint4*>(clp + (size_t)mc * CH + (kc * 4 + fg) * 8);
+  };
+  uint4 xb[2], xc[KC3], nb[2], nc[KC3];
+  load_frags(0, xb, xc);
+  for (int t = 0; t < kTailTPB; ++t) {
+    const int m0 = (blk * kTailTPB + t) * 64 + wave * 16;
+    if (m0 >= M) break;                                // wave-uniform
+    const int m = m0 + fr;
+    if (t + 1 < kTailTPB) load_frags(t + 1, nb, nc);
     // ---- box branch: logits -> LDS --------------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -499,6 +507,10 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int b
       else if (fg == 1) { o[4] = best >= p.conf ? best : 0.f; o[5] = (float)bi; }
     }
     __builtin_amdgcn_wave_barrier();                    // the next tile overwrites this wave's logits
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) xb[kc] = nb[kc];
+#pragma unroll
+    for (int kc = 0; kc < KC3; ++kc) xc[kc] = nc[kc];
   }
 }
 
