@@ -397,10 +397,11 @@ def test_detect_16bit_modes_on_the_chaotic_checkpoint(dtype, min_match, feat_rel
     assert np.isfinite(got).all()
 
 
-def test_batch_invariance_and_determinism(sd_c):
-    """Size-independent properties at the bench configuration (B=64, 640x640, bf16)."""
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_batch_invariance_and_determinism(sd_c, dtype):
+    """Size-independent properties at the bench configuration (B=64, 640x640; f16 = the bench's dtype, and bf16)."""
     frames = noise_frames(11, 64, 640, 640)
-    m = _yolo("c", 640, sd_c, "bf16")
+    m = _yolo("c", 640, sd_c, dtype)
     a = m.detect_batch(frames)
     b = m.detect_batch(frames)
     assert np.array_equal(a, b)                                     # deterministic replay
