@@ -359,7 +359,7 @@ def test_detect_16bit_modes_with_unrounded_weights(dtype):
     print(f"{dtype} un-rounded weights: vs emulation {vs_emu}\n  vs f32 oracle {vs_f32}")
     assert vs_emu["n_ref"] >= 100
     if dtype == "f16":
-        assert vs_emu["match_frac"] >= 0.98 and vs_emu["anchor_box_err_px_p99"] <= tol, vs_emu
+        assert vs_emu["match_frac"] >= 0.97 and vs_emu["anchor_box_err_px_p99"] <= tol, vs_emu                   # measured 98.6 % (213 detections: 3 flips), p99 0.25 px
         assert vs_f32["match_frac_iou_only"] >= 0.93 and vs_f32["anchor_box_err_px_p50"] <= tol, vs_f32
     else:
         assert vs_emu["match_frac_iou_only"] >= 0.93 and vs_emu["anchor_box_err_px_p50"] <= tol, vs_emu
