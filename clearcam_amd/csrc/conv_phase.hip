@@ -319,8 +319,10 @@ template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, in
     // Default: the persistent loop where a block walks at least ~2.5 tiles (same results bit for bit; r03 A/B on MI355X: CLIP GEMMs
     // +3-6 %, 1x1 convs at 80x80 / 160x160 +4-10 %, 3x3 256->256 at 80x80 +-1 %), one tile per block below that (400-tile layers at
     // 40x40: the persistent form measured 2-4 % slower - its second round is as ragged, and the first has no dispatch skew)
+    // 1x1 layers take it from one full round on (their tiles are short - K <= 512 at 40x40 - so the next tile's first DMA under the
+    // store epilogue is a larger share: 256 -> 256 at 40x40, 400 tiles: 34.0 -> 30.2 us, 512 -> 256: 44.2 -> 41.7; r03p)
     const long tiles = (long)((M + 255) / 256) * a.nt;
-    flags = (tiles >= 640 && conv_persist_ok(p)) ? 512 : 32;
+    flags = ((tiles >= 640 || (a.is1x1 && tiles > 256)) && conv_persist_ok(p)) ? 512 : 32;
   }
   ConvAux b = a; b.flags = flags;
   const size_t xb = (size_t)p.B * p.s0.H * p.s0.W * p.s0.cstride * sizeof(T), wbytes = (size_t)p.Cout * p.Kw * sizeof(T);

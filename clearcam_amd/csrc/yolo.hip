@@ -49,6 +49,12 @@ struct Op {
              // 7 fused DDetect tail (last 1x1 convs of both branches + decode)
   ConvP conv; PoolP pool; DecodeP dec; NmsP nms; FuseP fuse; StemP stem; CspP csp; HeadTailP tail;
   double alg_macs = 0;   // algorithmic multiply-accumulates of this launch (no padding / densification)
+  // Concurrency inside the captured graph: launches of one lane run in list order; a launch waits for the launches of OTHER lanes
+  // it conflicts with (read-after-write, write-after-read, write-after-write on overlapping channel ranges of a tensor, or on
+  // overlapping arena bytes of two tensors).  Lane 0 is the trunk; the list order itself is always a valid serial schedule.
+  struct Access { int buf, coff, C; bool write; };     // buf < 0: -2 = the (B, A, 6) decoded rows, -3 = the (B, 300, 6) result
+  int lane = 0;
+  std::vector<Access> acc;
 };
 
 struct Plan {
@@ -65,8 +71,10 @@ struct Plan {
   bool fused_stem = false; const void* last_frames = nullptr;   // no materialised network input; frames of the last detect call
   float* det = nullptr; float* out_dev = nullptr;
   hipGraphExec_t exec = nullptr;
+  std::vector<hipEvent_t> lane_ev;                     // the cross-lane edges of the captured graph (run_ops_lanes)
   ~Plan() {
     if (exec) hipGraphExecDestroy(exec);
+    for (hipEvent_t e : lane_ev) if (e) hipEventDestroy(e);
     for (void* p : {(void*)arena, (void*)xlo, (void*)xhi, (void*)ylo, (void*)yhi, (void*)xfr, (void*)yfr, frames_dev, (void*)det, (void*)out_dev})
       if (p) hipFree(p);
   }
@@ -80,6 +88,7 @@ struct cc_yolo {
   const Arch* arch = nullptr;
   int res = 640, dtype = BF16, device = 0;
   hipStream_t stream = nullptr;
+  std::vector<hipStream_t> side;                       // streams of lanes 1.. while a plan is captured (run_ops_lanes)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::map<std::string, HostTensor> host;
   std::map<std::string, PackedConv> packed;
@@ -143,6 +152,30 @@ struct Builder {
   cc_yolo* Y; Plan* P; const Arch& a;
   Builder(cc_yolo* y, Plan* p) : Y(y), P(p), a(*y->arch) {}
 
+  int cur_lane = 0;
+  // Which independent chains leave the trunk (CLEARCAM_LANES, read per plan): bit 1 = each DDetect level on its own lane (2-4), bit 2 =
+  // the three levels share lane 2, bit 0 = ADown's pooled half on lane 1.  Default: the DDetect levels, for plans of at least 16
+  // network-sized frames - there P3's 3x3 convs fill the CUs the neck's 40x40 / 20x20 launches leave idle (B = 64: 11.39 -> 11.24 ms,
+  // B = 16: 3.75 -> 3.67); a graph with branches costs ~50 us of extra synchronisation per replay, so small plans stay one chain
+  // (B = 8: 2.35 -> 2.39 ms, one frame 1.30 -> 1.35).  ADown's halves gained nothing at any size (both open with a bandwidth-bound
+  // pool).  profiles/r03o_lanes_ab*.txt.  Outputs are bit-identical either way.
+  int lanes_mask() const {
+    const char* e = getenv("CLEARCAM_LANES");
+    if (e) return atoi(e);
+    return (long)P->B * P->Hn * P->Wn >= 16L * 640 * 640 ? 2 : 0;
+  }
+  struct Lane {                                            // scope guard: launches pushed inside run on lane `l`
+    Builder& b; int saved;
+    Lane(Builder& b_, int l) : b(b_), saved(b_.cur_lane) {
+      const int m = b.lanes_mask();
+      if (l == 1 ? (m & 1) : (m & 6)) b.cur_lane = (l > 2 && (m & 4)) ? 2 : l;    // bit 2: all DDetect levels share lane 2
+    }
+    ~Lane() { b.cur_lane = saved; }
+  };
+  static Op::Access rd(View v) { return Op::Access{v.buf, v.coff, v.C, false}; }
+  static Op::Access wr(View v) { return Op::Access{v.buf, v.coff, v.C, true}; }
+  void push(Op& op, std::vector<Op::Access> acc) { op.lane = cur_lane; op.acc = std::move(acc); P->ops.push_back(op); }
+
   int new_buf(int H, int W, int C, bool f32 = false) {
     Buf b{H, W, C, f32, P->arena_bytes};
     size_t bytes = (size_t)P->B * H * W * C * (f32 ? 4 : dtype_size(Y->dtype));
@@ -201,7 +234,10 @@ struct Builder {
     else { c.res = (const void*)(intptr_t)-1; }
     c.act = act;
     op.alg_macs = (double)c.B * c.Ho * c.Wo * pc.macs_px;
-    P->ops.push_back(op);
+    std::vector<Op::Access> acc{wr(out)};
+    for (const In& in : ins) acc.push_back(rd(in.v));
+    if (res) acc.push_back(rd(*res));
+    push(op, std::move(acc));
   }
 
   // The detector's first conv straight from the frames (stem_fused_kernel); 16-bit storage only, CLEARCAM_FUSE_STEM=0 disables.
@@ -232,7 +268,7 @@ struct Builder {
     q.w = stem_weights(name, pc); q.bias = pc.bias; q.Cout = pc.cout;
     q.out = (void*)(intptr_t)out.buf; q.out_cstride = ob.C; q.out_coff = out.coff; q.Ho = ob.H; q.Wo = ob.W;
     op.alg_macs = (double)P->B * ob.H * ob.W * pc.macs_px;
-    P->ops.push_back(op);
+    push(op, {wr(out)});
     P->fused_stem = true;
   }
 
@@ -244,7 +280,7 @@ struct Builder {
     q.B = P->B; q.H = ib.H; q.W = ib.W; q.C = in.C; q.Ho = ob.H; q.Wo = ob.W; q.k = k; q.stride = stride; q.pad = pad; q.mode = mode;
     const int ph = mode == 2 ? ib.H - 1 : ib.H, pw = mode == 2 ? ib.W - 1 : ib.W;     // mode 2 pools the avg-pooled (H-1, W-1) map
     CC_CHECK(in.C == out.C && ob.H == (ph + 2 * pad - k) / stride + 1 && ob.W == (pw + 2 * pad - k) / stride + 1, "pool view mismatch");
-    P->ops.push_back(op);
+    push(op, {rd(in), wr(out)});
   }
 
   // ---- blocks (detection/yolov9.py:40-149) ---------------------------------------------------
@@ -285,7 +321,7 @@ struct Builder {
     { const char* e = dev_env("CLEARCAM_CSP_DBG"); q.dbg = e ? atoi(e) : 0; }       // stops the kernel after stage 1-3: WRONG outputs
     { const char* e = dev_env("CLEARCAM_CSP_STREAM"); q.stream = e ? atoi(e) : 0; }
     op.alg_macs = (double)P->B * ib.H * ib.W * (c12.macs_px + cr.macs_px + cb.macs_px + c3.macs_px);
-    P->ops.push_back(op);
+    push(op, {rd(in), wr(out)});
   }
 
   // RepNCSP (:92-105) + trailing 3x3 Conv (:112,115): in -> out
@@ -351,7 +387,21 @@ struct Builder {
     if (a.adown) {
       CC_CHECK(C == cout, "ADown keeps the channel count");
       // x.avg_pool2d(2,1,0).chunk(2,1): only the half the strided conv reads is materialised at full resolution;
-      // the other half goes avg -> max-pool in one pass (avgmax_pool_kernel)
+      // the other half goes avg -> max-pool in one pass (avgmax_pool_kernel).  The two halves are independent chains (a bandwidth-
+      // bound pool + thin 1x1 beside a pool + 3x3): the pooled half is listed first and runs on lane 1 beside the trunk.
+      {
+        Lane lane(*this, 1);
+        const int mp = new_buf(Ho, Wo, C / 2);
+        const int E = Y->dtype == F32 ? 4 : 8;
+        if ((C / 2) % E == 0 && in.coff % E == 0 && P->bufs[in.buf].C % E == 0) {
+          pool(slice(in, C / 2, C / 2), whole(mp), 3, 2, 1, 2);
+        } else {                                               // channel counts off the 16-byte grid (yolov9-m): two passes
+          const int avg2 = new_buf(H - 1, W - 1, C / 2);
+          pool(slice(in, C / 2, C / 2), whole(avg2), 2, 1, 0, 0);
+          pool(whole(avg2), whole(mp), 3, 2, 1, 1);
+        }
+        conv({{whole(mp), 0}}, pconv({p + ".cv2.conv"}, {1}), slice(whole(o), C / 2, C / 2), 1, 1);
+      }
       if (fuse_adown(slice(in, 0, C / 2))) {
         conv({{slice(in, 0, C / 2), -1}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(o), 0, C / 2), 2, 1);   // average in the conv's loader
       } else {
@@ -359,16 +409,6 @@ struct Builder {
         pool(slice(in, 0, C / 2), whole(avg), 2, 1, 0, 0);
         conv({{whole(avg), 0}}, pconv({p + ".cv1.conv"}, {1}), slice(whole(o), 0, C / 2), 2, 1);
       }
-      const int mp = new_buf(Ho, Wo, C / 2);
-      const int E = Y->dtype == F32 ? 4 : 8;
-      if ((C / 2) % E == 0 && in.coff % E == 0 && P->bufs[in.buf].C % E == 0) {
-        pool(slice(in, C / 2, C / 2), whole(mp), 3, 2, 1, 2);
-      } else {                                               // channel counts off the 16-byte grid (yolov9-m): two passes
-        const int avg2 = new_buf(H - 1, W - 1, C / 2);
-        pool(slice(in, C / 2, C / 2), whole(avg2), 2, 1, 0, 0);
-        pool(whole(avg2), whole(mp), 3, 2, 1, 1);
-      }
-      conv({{whole(mp), 0}}, pconv({p + ".cv2.conv"}, {1}), slice(whole(o), C / 2, C / 2), 1, 1);
     } else {
       const int avg = new_buf(H - 1, W - 1, C);
       pool(in, whole(avg), 2, 1, 0, 0);
@@ -408,7 +448,9 @@ struct Builder {
       f.in[k] = (const void*)(intptr_t)v.buf; f.H[k] = b.H; f.W[k] = b.W; f.cstride[k] = b.C; f.coff[k] = v.coff; f.shift[k] = sh;
     }
     f.out = (void*)(intptr_t)o; f.out_cstride = last.C; f.out_coff = 0; f.B = P->B; f.Ho = lb.H; f.Wo = lb.W; f.C = last.C;
-    P->ops.push_back(op);
+    std::vector<Op::Access> acc{wr(whole(o)), rd(last)};
+    for (const View& v : parts) acc.push_back(rd(v));
+    push(op, std::move(acc));
     return whole(o);
   }
 
@@ -419,41 +461,50 @@ struct Builder {
     const char* e = getenv("CLEARCAM_FUSE_HEAD");
     return (!e || atoi(e) != 0) && head_tail_supported(Y->dtype, a.cls_hidden);
   }
-  void head(const std::string& H22, const View (&feats)[3]) {
-    Op dec{}; dec.kind = 2;
-    Op tail{}; tail.kind = 7;
+  // One level of DDetect (:157-220): the level's conv chain runs on its own lane - it only needs that level's feature map, so
+  // P3's 1.3 ms of 3x3 convs overlap the neck's way down to P4 / P5 (whose 40x40 / 20x20 launches leave CUs idle) instead of queueing
+  // behind it.  head_finish() joins the three lanes.
+  Op head_dec{}, head_tail{};
+  std::vector<Op::Access> head_acc;
+  int head_levels = 0;
+  void head_level(const std::string& H22, int l, View feat) {
+    Lane lane(*this, 2 + l);
     const bool fused = fuse_head_tail();
-    P->A = 0;
-    for (int l = 0; l < 3; ++l) {
-      const std::string hb = H22 + "cv2.list." + std::to_string(l) + ".list.", hc = H22 + "cv3.list." + std::to_string(l) + ".list.";
-      const int H = P->bufs[feats[l].buf].H, W = P->bufs[feats[l].buf].W, ch = a.cls_hidden;
-      const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch);
-      conv({{feats[l], 0}}, pconv({hb + "0.conv", hc + "0.conv"}, {1, 1}), whole(hbuf), 1, 1);
-      conv({{slice(whole(hbuf), 0, 64), 0}}, pconv({hb + "1.conv"}, {4}), whole(bxb), 1, 1);
-      conv({{slice(whole(hbuf), 64, ch), 0}}, pconv({hc + "1.conv"}, {1}), whole(clb), 1, 1);
-      const PackedConv &c2 = pconv({hb + "2"}, {4}), &c3 = pconv({hc + "2"}, {1});
-      if (fused) {
-        CC_CHECK(c2.cin == 64 && c2.cout == 64 && c2.k == 1 && c3.cin == ch && c3.cout == 80 && c3.k == 1, "fused DDetect tail: unexpected conv shapes");
-        HeadTailP& q = tail.tail;
-        q.bx[l] = (const void*)(intptr_t)bxb; q.cl[l] = (const void*)(intptr_t)clb;
-        q.w2[l] = c2.w; q.w3[l] = c3.w; q.b2[l] = c2.bias; q.b3[l] = c3.bias; q.kw2 = c2.kw; q.kw3 = c3.kw;
-        q.H[l] = H; q.W[l] = W;
-      } else {
-        const int raw = new_buf(H, W, 144, true);
-        conv({{whole(bxb), 0}}, c2, slice(whole(raw), 0, 64), 1, 0);
-        conv({{whole(clb), 0}}, c3, slice(whole(raw), 64, 80), 1, 0);
-        P->taps["raw" + std::to_string(l)] = raw;
-        dec.dec.raw[l] = (const float*)(intptr_t)raw; dec.dec.H[l] = H; dec.dec.W[l] = W;
-      }
-      P->A += H * W;
-    }
+    if (head_levels++ == 0) { head_dec = Op{}; head_dec.kind = 2; head_tail = Op{}; head_tail.kind = 7; head_acc.clear(); P->A = 0; }
+    const std::string hb = H22 + "cv2.list." + std::to_string(l) + ".list.", hc = H22 + "cv3.list." + std::to_string(l) + ".list.";
+    const int H = P->bufs[feat.buf].H, W = P->bufs[feat.buf].W, ch = a.cls_hidden;
+    const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch);
+    conv({{feat, 0}}, pconv({hb + "0.conv", hc + "0.conv"}, {1, 1}), whole(hbuf), 1, 1);
+    conv({{slice(whole(hbuf), 0, 64), 0}}, pconv({hb + "1.conv"}, {4}), whole(bxb), 1, 1);
+    conv({{slice(whole(hbuf), 64, ch), 0}}, pconv({hc + "1.conv"}, {1}), whole(clb), 1, 1);
+    const PackedConv &c2 = pconv({hb + "2"}, {4}), &c3 = pconv({hc + "2"}, {1});
     if (fused) {
-      HeadTailP& q = tail.tail;
-      q.B = P->B; q.A = P->A; q.ch = a.cls_hidden; q.dfl_w = Y->dfl_w; q.conf = 0.25f;
-      P->ops.push_back(tail);
+      CC_CHECK(c2.cin == 64 && c2.cout == 64 && c2.k == 1 && c3.cin == ch && c3.cout == 80 && c3.k == 1, "fused DDetect tail: unexpected conv shapes");
+      HeadTailP& q = head_tail.tail;
+      q.bx[l] = (const void*)(intptr_t)bxb; q.cl[l] = (const void*)(intptr_t)clb;
+      q.w2[l] = c2.w; q.w3[l] = c3.w; q.b2[l] = c2.bias; q.b3[l] = c3.bias; q.kw2 = c2.kw; q.kw3 = c3.kw;
+      q.H[l] = H; q.W[l] = W;
+      head_acc.push_back(rd(whole(bxb))); head_acc.push_back(rd(whole(clb)));
     } else {
-      dec.dec.B = P->B; dec.dec.A = P->A; dec.dec.dfl_w = Y->dfl_w; dec.dec.conf = 0.25f;
-      P->ops.push_back(dec);
+      const int raw = new_buf(H, W, 144, true);
+      conv({{whole(bxb), 0}}, c2, slice(whole(raw), 0, 64), 1, 0);
+      conv({{whole(clb), 0}}, c3, slice(whole(raw), 64, 80), 1, 0);
+      P->taps["raw" + std::to_string(l)] = raw;
+      head_dec.dec.raw[l] = (const float*)(intptr_t)raw; head_dec.dec.H[l] = H; head_dec.dec.W[l] = W;
+      head_acc.push_back(rd(whole(raw)));
+    }
+    P->A += H * W;
+  }
+  void head_finish() {
+    CC_CHECK(head_levels == 3, "DDetect has three levels");
+    head_acc.push_back(Op::Access{-2, 0, 1, true});
+    if (fuse_head_tail()) {
+      HeadTailP& q = head_tail.tail;
+      q.B = P->B; q.A = P->A; q.ch = a.cls_hidden; q.dfl_w = Y->dfl_w; q.conf = 0.25f;
+      push(head_tail, head_acc);
+    } else {
+      head_dec.dec.B = P->B; head_dec.dec.A = P->A; head_dec.dec.dfl_w = Y->dfl_w; head_dec.dec.conf = 0.25f;
+      push(head_dec, head_acc);
     }
     Op nms{}; nms.kind = 3;
     nms.nms.B = P->B; nms.nms.A = P->A; nms.nms.iou_thr = 0.45f;
@@ -462,7 +513,7 @@ struct Builder {
     nms.nms.gain = (float)gain;
     nms.nms.pad_x = (float)((P->Wn - P->W * gain) / 2); nms.nms.pad_y = (float)((P->Hn - P->H * gain) / 2);
     nms.nms.src_w = (float)P->W; nms.nms.src_h = (float)P->H;
-    P->ops.push_back(nms);
+    push(nms, {Op::Access{-2, 0, 1, false}, Op::Access{-3, 0, 1, true}});
   }
 
   void build_e() {   // detection/yolov9.py:328-371
@@ -500,13 +551,15 @@ struct Builder {
     const View y29 = sppelan(M + "29", y28, 256, 512);
     const View y32 = elan4(M + "32", {{y29, 1}, {y25, 0}}, 128, 512);
     const View y35 = elan4(M + "35", {{y32, 1}, {y22, 0}}, 64, 256);
+    head_level(M + "42.", 0, y35);
     const View y36 = down(M + "36", y35, 256);
     const View y38 = elan4(M + "38", {{y36, 0}, {y32, 0}}, 128, 512);
+    head_level(M + "42.", 1, y38);
     const View y39 = down(M + "39", y38, 512);
     const View y41 = elan4(M + "41", {{y39, 0}, {y29, 0}}, 256, 512);
+    head_level(M + "42.", 2, y41);
     P->taps["p3"] = y35.buf; P->taps["p4"] = y38.buf; P->taps["p5"] = y41.buf;
-    const View feats[3] = {y35, y38, y41};
-    head(M + "42.", feats);
+    head_finish();
   }
 
   void build() {
@@ -531,15 +584,15 @@ struct Builder {
     const View y9 = sppelan(M + "9", y8, a.spp_hidden, a.p5);
     const View y12 = elan4(M + "12", {{y9, 1}, {y6, 0}}, a.e6_hidden, a.p4);
     const View y15 = elan4(M + "15", {{y12, 1}, {y4, 0}}, a.e4_hidden, a.p3);
+    head_level(M + "22.", 0, y15);                               // DDetect (:157-220), each level as soon as its map exists
     const View y16 = down(M + "16", y15, a.d16_out);
     const View y18 = elan4(M + "18", {{y16, 0}, {y12, 0}}, a.e6_hidden, a.p4);
+    head_level(M + "22.", 1, y18);
     const View y19 = down(M + "19", y18, a.d19_out);
     const View y21 = elan4(M + "21", {{y19, 0}, {y9, 0}}, a.e8_hidden, a.p5);
+    head_level(M + "22.", 2, y21);
     P->taps["p3"] = y15.buf; P->taps["p4"] = y18.buf; P->taps["p5"] = y21.buf;
-
-    // DDetect (:157-220)
-    const View feats[3] = {y15, y18, y21};
-    head(M + "22.", feats);
+    head_finish();
   }
 
   // Arena packing: a buffer lives from the first launch that touches it to the last; buffers whose lifetimes do not
@@ -565,6 +618,23 @@ struct Builder {
       else if (op.kind == 5) touch(op.stem.out, -1);           // runs before the graph, whatever its position in the list
       else if (op.kind == 6) { touch(op.csp.x, t); touch(op.csp.out, t); }
       else if (op.kind == 7) { for (int l = 0; l < 3; ++l) { touch(op.tail.bx[l], t); touch(op.tail.cl[l], t); } }
+    }
+    // A launch on a side lane may run as late as its join: the first later launch of another lane that conflicts with that lane's
+    // work from there on.  What it touches stays live until then (trunk launches never run later than their place in the list).
+    auto same_tensor_conflict = [](const Op& x, const Op& y) {
+      for (const Op::Access& p : x.acc) for (const Op::Access& q : y.acc)
+        if ((p.write || q.write) && p.buf == q.buf && p.coff < q.coff + q.C && q.coff < p.coff + p.C) return true;
+      return false;
+    };
+    for (int t = 0; t < nops; ++t) {
+      const Op& op = P->ops[t];
+      if (op.lane == 0) continue;
+      int join = nops;
+      for (int u = t + 1; u < nops && join == nops; ++u) {
+        if (P->ops[u].lane == op.lane) continue;
+        for (int v = t; v < u; ++v) if (P->ops[v].lane == op.lane && same_tensor_conflict(P->ops[v], P->ops[u])) { join = u; break; }
+      }
+      for (const Op::Access& x : op.acc) if (x.buf >= 0) last[x.buf] = std::max(last[x.buf], join);
     }
     first[P->in_buf] = -1;                                     // written by the letterbox kernel before the first op
     for (auto& kv : P->taps) last[kv.second] = nops + 1;       // cc_yolo_get_tensor reads these after the run
@@ -668,6 +738,63 @@ static void run_ops(cc_yolo* Y, Plan* P, hipStream_t s) {
   for (const Op& op : P->ops) launch_op(Y->dtype, P, op, s, false);
 }
 
+// Two launches conflict when one writes what the other touches: overlapping channel ranges of one tensor, or overlapping arena bytes
+// of two tensors that share memory (pack_arena).
+static bool ops_conflict(const cc_yolo* Y, const Plan* P, const Op& x, const Op& y) {
+  auto bytes = [&](int i) { const Buf& b = P->bufs[i]; return (size_t)P->B * b.H * b.W * b.C * (b.f32 ? 4 : dtype_size(Y->dtype)); };
+  for (const Op::Access& p : x.acc)
+    for (const Op::Access& q : y.acc) {
+      if (!(p.write || q.write)) continue;
+      if (p.buf < 0 || q.buf < 0) { if (p.buf == q.buf) return true; continue; }
+      if (p.buf == q.buf) { if (p.coff < q.coff + q.C && q.coff < p.coff + p.C) return true; continue; }
+      const size_t po = P->bufs[p.buf].off, qo = P->bufs[q.buf].off;
+      if (po < qo + bytes(q.buf) && qo < po + bytes(p.buf)) return true;
+    }
+  return false;
+}
+
+// The plan under capture with its lanes as streams: lane 0 is the capturing stream, every other lane a side stream that joins the
+// capture by waiting for an event of it.  A launch waits for the LAST conflicting launch of each other lane (stream order covers the
+// earlier ones); all lanes are joined back before the capture ends.  Events recorded under capture are graph edges, not nodes.
+static void run_ops_lanes(cc_yolo* Y, Plan* P, hipStream_t s) {
+  const int nops = (int)P->ops.size();
+  int nl = 1;
+  for (const Op& op : P->ops) nl = std::max(nl, op.lane + 1);
+  if (nl == 1) { run_ops(Y, P, s); return; }
+  while ((int)Y->side.size() < nl - 1) { hipStream_t t; CC_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); Y->side.push_back(t); }
+  auto stream_of = [&](int lane) { return lane == 0 ? s : Y->side[lane - 1]; };
+  std::vector<hipEvent_t>& ev = P->lane_ev;             // owned by the plan: they outlive the capture
+  ev.assign(nops + 1, nullptr);
+  {
+    std::vector<char> joined(nl, 0); joined[0] = 1;
+    std::vector<std::vector<int>> seen(nl, std::vector<int>(nl, -1));   // seen[l][m]: last launch of lane m that lane l has waited for
+    std::vector<int> tail(nl, -1);                                       // last launch of each lane
+    for (int i = 0; i < nops; ++i) {
+      const Op& op = P->ops[i];
+      if (op.kind == 5) continue;                                        // runs before the graph
+      const int l = op.lane; hipStream_t st = stream_of(l);
+      std::vector<int> need(nl, -1);
+      for (int j = 0; j < i; ++j) { const Op& o = P->ops[j]; if (o.kind != 5 && o.lane != l && ops_conflict(Y, P, op, o)) need[o.lane] = j; }
+      bool waited = false;
+      for (int m = 0; m < nl; ++m) if (need[m] > seen[l][m]) {
+        CC_HIP(hipStreamWaitEvent(st, ev[need[m]], 0)); seen[l][m] = need[m]; waited = true;
+      }
+      if (!joined[l]) {
+        if (!waited) {                                                   // no producer on another lane: fork from the trunk's current point
+          if (!ev[nops]) CC_HIP(hipEventCreateWithFlags(&ev[nops], hipEventDisableTiming));
+          CC_HIP(hipEventRecord(ev[nops], s)); CC_HIP(hipStreamWaitEvent(st, ev[nops], 0));
+        }
+        joined[l] = 1;
+      }
+      launch_op(Y->dtype, P, op, st, false);
+      CC_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+      CC_HIP(hipEventRecord(ev[i], st));
+      tail[l] = i;
+    }
+    for (int m = 1; m < nl; ++m) if (joined[m] && tail[m] > seen[0][m]) CC_HIP(hipStreamWaitEvent(s, ev[tail[m]], 0));
+  }
+}
+
 // The fused letterbox + first conv launches read the caller's frames, whose address changes from call to call, so they
 // stay outside the captured graph and run right before it.
 static void run_stems(cc_yolo* Y, Plan* P, const void* frames, hipStream_t s) {
@@ -699,7 +826,7 @@ static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32) {
   // capture the launch list once; replay afterwards (the TinyJit role, helpers.py:214-221)
   hipGraph_t graph = nullptr;
   CC_HIP(hipStreamBeginCapture(Y->stream, hipStreamCaptureModeThreadLocal));
-  try { run_ops(Y, P.get(), Y->stream); } catch (...) { hipStreamEndCapture(Y->stream, &graph); if (graph) hipGraphDestroy(graph); throw; }
+  try { run_ops_lanes(Y, P.get(), Y->stream); } catch (...) { hipStreamEndCapture(Y->stream, &graph); if (graph) hipGraphDestroy(graph); throw; }
   CC_HIP(hipStreamEndCapture(Y->stream, &graph));
   CC_HIP(hipGraphInstantiate(&P->exec, graph, nullptr, nullptr, 0));
   CC_HIP(hipGraphDestroy(graph));
@@ -987,6 +1114,7 @@ void cc_yolo_destroy(cc_yolo* h) {
   if (h->dfl_w) hipFree(h->dfl_w);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
+  for (hipStream_t t : h->side) hipStreamDestroy(t);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }

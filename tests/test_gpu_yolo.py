@@ -569,6 +569,41 @@ def test_fused_ddetect_tail_equals_unfused(size, res, dtype, shape):
     assert (c1[..., 4] > 0).sum() > 0 and np.isfinite(c1).all()
 
 
+@pytest.mark.parametrize("size,res,dtype,shape", [
+    ("c", 640, "f16", (3, 640, 640, 3)),          # the bench network
+    ("c", 640, "f32", (2, 270, 480, 3)),          # f32: the unfused DDetect tail (five launches per level + decode) on its lanes
+    ("t", 320, "bf16", (4, 320, 320, 3)),         # ELAN1 + AConv graph (no pooled ADown half)
+    ("e", 640, "f16", (1, 640, 640, 3)),          # the 43-block graph: CBLinear / CBFuse between the lanes' producers
+])
+def test_concurrent_lanes_equal_one_chain(size, res, dtype, shape):
+    """The captured plan with independent chains on their own streams (each DDetect level on a lane, ADown's pooled half on another:
+    CLEARCAM_LANES=3, every fork the builder knows) against the same launches as ONE chain (CLEARCAM_LANES=0).  The kernels are the
+    same and deterministic, so detections and every decoded row must be IDENTICAL - a missing dependency edge or a buffer shared
+    between two launches that may now overlap would show as a difference (or as NaNs) on some replay; three replays each."""
+    from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict
+    sd = conditioned_yolov9_state_dict("c", 1234) if size == "c" else synthetic_yolov9_state_dict(size, 1234)
+    frames = noise_frames(9, *shape[:3])
+    got = {}
+    for label, env in (("chain", "0"), ("lanes", "3"), ("one_head_lane", "5")):
+        os.environ["CLEARCAM_LANES"] = env                                    # read when the plan is built (first call of a shape)
+        try:
+            m = _yolo(size, res, sd, dtype)
+            runs = []
+            for _ in range(3):
+                det = m.detect_batch(frames)
+                runs.append((det, m.get_tensor("decoded"), m.get_tensor("p3"), m.get_tensor("p5")))
+            got[label] = runs
+            m.close()
+        finally:
+            os.environ.pop("CLEARCAM_LANES", None)
+    ref = got["chain"][0]
+    assert (ref[1][..., 4] > 0).sum() > 0 and np.isfinite(ref[1]).all()
+    for label, runs in got.items():
+        for det, dec, p3, p5 in runs:
+            assert np.array_equal(det, ref[0]) and np.array_equal(dec, ref[1]), label
+            assert np.array_equal(p3, ref[2]) and np.array_equal(p5, ref[3]), label
+
+
 _ADOWN_SCRIPT = r"""
 import csv, os, sys, numpy as np
 from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict

@@ -43,6 +43,8 @@ SHAPES = [
     ("1x1 768->512 @40x40 B64", 64, 40, 40, 768, 512, 1, 1, 1),
     ("1x1 512->512 @40x40 B64", 64, 40, 40, 512, 512, 1, 1, 1),
     ("1x1 512->256 @80x80 B64", 64, 80, 80, 512, 256, 1, 1, 1),
+    ("1x1 256->256 @40x40 B64 (400 tiles)", 64, 40, 40, 256, 256, 1, 1, 1),
+    ("1x1 512->256 @40x40 B64 (400 tiles)", 64, 40, 40, 512, 256, 1, 1, 1),
 ]
 
 
