@@ -89,6 +89,12 @@ struct cc_yolo {
   int res = 640, dtype = BF16, device = 0;
   hipStream_t stream = nullptr;
   std::vector<hipStream_t> side;                       // streams of lanes 1.. while a plan is captured (run_ops_lanes)
+  // Batches in flight (cc_yolo_submit / cc_yolo_wait): slot i > 0 has its own stream and its own plans (arena, graph), so the tail of
+  // one batch overlaps the head of the next; slot 0 is `stream` and the plans cc_yolo_detect uses.
+  std::vector<hipStream_t> slot_stream;
+  std::vector<hipEvent_t> slot_done;
+  long long submitted = 0;
+  hipStream_t stream_of_slot(int i) const { return i == 0 ? stream : slot_stream[i - 1]; }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::map<std::string, HostTensor> host;
   std::map<std::string, PackedConv> packed;
@@ -162,6 +168,7 @@ struct Builder {
   int lanes_mask() const {
     const char* e = getenv("CLEARCAM_LANES");
     if (e) return atoi(e);
+    if (!Y->slot_stream.empty()) return 0;                     // batches in flight already fill those CUs with the next batch
     return (long)P->B * P->Hn * P->Wn >= 16L * 640 * 640 ? 2 : 0;
   }
   struct Lane {                                            // scope guard: launches pushed inside run on lane `l`
@@ -801,8 +808,8 @@ static void run_stems(cc_yolo* Y, Plan* P, const void* frames, hipStream_t s) {
   for (Op& op : P->ops) if (op.kind == 5) { op.stem.pre.frames = frames; launch_stem_fused(Y->dtype, op.stem, s); }
 }
 
-static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32) {
-  const std::vector<int> key{B, H, W, frame_f32};
+static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32, int slot = 0) {
+  const std::vector<int> key{B, H, W, frame_f32, slot};
   if (Plan* hit = Y->plans.find(key)) return hit;
   std::unique_ptr<Plan> P(new Plan());
   P->B = B; P->H = H; P->W = W; P->frame_f32 = frame_f32;
@@ -831,7 +838,10 @@ static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32) {
   CC_HIP(hipGraphInstantiate(&P->exec, graph, nullptr, nullptr, 0));
   CC_HIP(hipGraphDestroy(graph));
   // a plan that cc_yolo_get_tensor / cc_yolo_profile still point at must not dangle when it is evicted
-  return Y->plans.insert(key, std::move(P), Y->stream, [&](Plan* gone) { if (Y->last == gone) Y->last = nullptr; });
+  return Y->plans.insert(key, std::move(P), Y->stream, [&](Plan* gone) {
+    for (hipStream_t t : Y->slot_stream) hipStreamSynchronize(t);        // the evicted plan may be running on a slot's stream
+    if (Y->last == gone) Y->last = nullptr;
+  });
 }
 
 }  // namespace cc
@@ -903,24 +913,11 @@ int cc_yolo_finalize(cc_yolo* h) {
   CC_API_END
 }
 
-int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int frame_f32, int frames_on_device,
-                   float* out, int out_on_device, void* stream) {
-  CC_API_BEGIN
-  CC_CHECK(h && frames && out, "null argument");
-  CC_CHECK(h->finalized, "cc_yolo_detect before cc_yolo_finalize");
-  CC_CHECK(B > 0 && H > 0 && W > 0, "bad frame shape");
-  CC_HIP(hipSetDevice(h->device));
-  Plan* P = get_plan(h, B, H, W, frame_f32 ? 1 : 0);
-  hipStream_t s = h->stream;
-  if (stream) {   // order our stream after the caller's
-    hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    CC_HIP(hipEventRecord(e, (hipStream_t)stream)); CC_HIP(hipStreamWaitEvent(s, e, 0)); CC_HIP(hipEventDestroy(e));
-  }
-  const void* fdev = frames;
-  if (!frames_on_device) { CC_HIP(hipMemcpyAsync(P->frames_dev, frames, P->frames_bytes, hipMemcpyHostToDevice, s)); fdev = P->frames_dev; }
-  CC_HIP(hipEventRecord(h->ev0, s));
+// One batch through plan P on stream s: the letterbox (or the fused letterbox + first conv launches, which read the caller's frames)
+// and then the captured graph.
+static void enqueue_step(cc_yolo* h, Plan* P, hipStream_t s, const void* fdev) {
   PreP pp{};
-  pp.frames = fdev; pp.frame_f32 = P->frame_f32; pp.B = B; pp.H = H; pp.W = W;
+  pp.frames = fdev; pp.frame_f32 = P->frame_f32; pp.B = P->B; pp.H = P->H; pp.W = P->W;
   pp.nh = P->nh; pp.nw = P->nw; pp.pad_y = P->pad_y; pp.pad_x = P->pad_x; pp.Hn = P->Hn; pp.Wn = P->Wn;
   pp.xlo = P->xlo; pp.xhi = P->xhi; pp.xfr = P->xfr; pp.ylo = P->ylo; pp.yhi = P->yhi; pp.yfr = P->yfr;
   pp.out = P->arena + P->bufs[P->in_buf].off; pp.out_c = P->bufs[P->in_buf].C;
@@ -938,6 +935,25 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
     }
   } else
   CC_HIP(hipGraphLaunch(P->exec, s));
+}
+
+int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int frame_f32, int frames_on_device,
+                   float* out, int out_on_device, void* stream) {
+  CC_API_BEGIN
+  CC_CHECK(h && frames && out, "null argument");
+  CC_CHECK(h->finalized, "cc_yolo_detect before cc_yolo_finalize");
+  CC_CHECK(B > 0 && H > 0 && W > 0, "bad frame shape");
+  CC_HIP(hipSetDevice(h->device));
+  Plan* P = get_plan(h, B, H, W, frame_f32 ? 1 : 0);
+  hipStream_t s = h->stream;
+  if (stream) {   // order our stream after the caller's
+    hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CC_HIP(hipEventRecord(e, (hipStream_t)stream)); CC_HIP(hipStreamWaitEvent(s, e, 0)); CC_HIP(hipEventDestroy(e));
+  }
+  const void* fdev = frames;
+  if (!frames_on_device) { CC_HIP(hipMemcpyAsync(P->frames_dev, frames, P->frames_bytes, hipMemcpyHostToDevice, s)); fdev = P->frames_dev; }
+  CC_HIP(hipEventRecord(h->ev0, s));
+  enqueue_step(h, P, s, fdev);
   CC_HIP(hipEventRecord(h->ev1, s));
   const size_t ob = (size_t)B * CC_MAX_DET * 6 * 4;
   if (out_on_device) {
@@ -954,13 +970,70 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
   CC_API_END
 }
 
+// taps and profilers read what the last call left behind: every stream of the handle has to be idle
+static void sync_all(cc_yolo* h) {
+  CC_HIP(hipStreamSynchronize(h->stream));
+  for (hipStream_t t : h->slot_stream) CC_HIP(hipStreamSynchronize(t));
+}
+
+int cc_yolo_set_in_flight(cc_yolo* h, int n) {
+  CC_API_BEGIN
+  CC_CHECK(h && n >= 1 && n <= 8, "in-flight depth must be 1..8");
+  CC_HIP(hipSetDevice(h->device));
+  sync_all(h);
+  h->plans.clear();                                     // plans are built for one depth (lanes on or off) and belong to a slot
+  h->last = nullptr;
+  while ((int)h->slot_stream.size() > n - 1) { hipStreamDestroy(h->slot_stream.back()); h->slot_stream.pop_back(); }
+  while ((int)h->slot_stream.size() < n - 1) { hipStream_t t; CC_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); h->slot_stream.push_back(t); }
+  while ((int)h->slot_done.size() > n) { hipEventDestroy(h->slot_done.back()); h->slot_done.pop_back(); }
+  while ((int)h->slot_done.size() < n) { hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->slot_done.push_back(e); }
+  h->submitted = 0;
+  CC_API_END
+}
+
+int cc_yolo_submit(cc_yolo* h, const void* frames_dev, int B, int H, int W, int frame_f32, float* out_dev, void* stream, long long* ticket) {
+  CC_API_BEGIN
+  CC_CHECK(h && frames_dev && out_dev && ticket, "null argument");
+  CC_CHECK(h->finalized, "cc_yolo_submit before cc_yolo_finalize");
+  CC_CHECK(B > 0 && H > 0 && W > 0, "bad frame shape");
+  CC_HIP(hipSetDevice(h->device));
+  if (h->slot_done.empty()) { hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->slot_done.push_back(e); }
+  const int depth = (int)h->slot_stream.size() + 1, slot = (int)(h->submitted % depth);
+  Plan* P = get_plan(h, B, H, W, frame_f32 ? 1 : 0, slot);
+  hipStream_t s = h->stream_of_slot(slot);
+  if (stream) {   // the frames are ready on the caller's stream; the caller's stream is NOT made to wait for the result (cc_yolo_wait does that)
+    hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CC_HIP(hipEventRecord(e, (hipStream_t)stream)); CC_HIP(hipStreamWaitEvent(s, e, 0)); CC_HIP(hipEventDestroy(e));
+  }
+  enqueue_step(h, P, s, frames_dev);
+  CC_HIP(hipMemcpyAsync(out_dev, P->out_dev, (size_t)B * CC_MAX_DET * 6 * 4, hipMemcpyDeviceToDevice, s));
+  CC_HIP(hipEventRecord(h->slot_done[slot], s));
+  h->last = P;
+  *ticket = h->submitted++;
+  CC_API_END
+}
+
+int cc_yolo_wait(cc_yolo* h, long long ticket, void* stream) {
+  CC_API_BEGIN
+  CC_CHECK(h, "null handle");
+  const int depth = (int)h->slot_stream.size() + 1;
+  CC_CHECK(ticket >= 0 && ticket < h->submitted, "no such submission");
+  // a slot's stream runs its submissions in order: once a LATER submission of the same slot has been recorded, the slot's event
+  // stands for that one, which finishes after this one - waiting for it is still correct (only later than necessary)
+  CC_HIP(hipSetDevice(h->device));
+  hipEvent_t e = h->slot_done[(int)(ticket % depth)];
+  if (stream) CC_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+  else CC_HIP(hipEventSynchronize(e));
+  CC_API_END
+}
+
 int cc_yolo_get_tensor(cc_yolo* h, const char* name, float* out, int64_t* shape, int* ndim) {
   CC_API_BEGIN
   CC_CHECK(h && name && shape && ndim, "null argument");
   CC_CHECK(h->last, "no detect call yet");
   Plan* P = h->last;
   CC_HIP(hipSetDevice(h->device));
-  CC_HIP(hipStreamSynchronize(h->stream));
+  sync_all(h);
   if (!strcmp(name, "decoded")) {
     shape[0] = P->B; shape[1] = P->A; shape[2] = 6; *ndim = 3;
     if (out) CC_HIP(hipMemcpy(out, P->det, (size_t)P->B * P->A * 24, hipMemcpyDeviceToHost));
@@ -1010,6 +1083,7 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
   CC_CHECK(h && ms && h->last && iters > 0, "bad argument / no detect call yet");
   Plan* P = h->last;
   CC_HIP(hipSetDevice(h->device));
+  sync_all(h);
   hipStream_t s = h->stream;
   const size_t n = P->ops.size();
   std::vector<hipEvent_t> ev(2 * n);
@@ -1081,7 +1155,7 @@ int cc_yolo_profile_graph(cc_yolo* h, int iters, int which, float* ms_per_replay
   Plan* P = h->last;
   CC_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  CC_HIP(hipStreamSynchronize(s));
+  sync_all(h);
   hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
   CC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   try {
@@ -1109,12 +1183,15 @@ void cc_yolo_destroy(cc_yolo* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  for (hipStream_t t : h->slot_stream) hipStreamSynchronize(t);
   h->plans.clear();
   for (auto& kv : h->packed) { hipFree(kv.second.w); hipFree(kv.second.bias); }
   if (h->dfl_w) hipFree(h->dfl_w);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   for (hipStream_t t : h->side) hipStreamDestroy(t);
+  for (hipStream_t t : h->slot_stream) hipStreamDestroy(t);
+  for (hipEvent_t e : h->slot_done) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }

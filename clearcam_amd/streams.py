@@ -6,10 +6,11 @@ process per GPU serves N cameras per step (BASELINE.json configs[3]: 1080p camer
 
   decode thread / synthetic source  writes frames into a PINNED host ring per camera (no per-frame allocation)
   copy stream                       N x hipMemcpyAsync ring slot -> slot of the device batch   (overlaps compute)
-  model stream                      letterbox (bit-exact u8 bilinear) + 144 convs + decode + top-300/NMS, one launch chain
+  model slots                       letterbox (bit-exact u8 bilinear) + 144 convs + decode + top-300/NMS, one captured graph per slot;
+                                    `depth` batches in flight (YOLOv9.submit: the last layers of a batch overlap the first of the next)
   copy back                         (N,300,6) float32 -> pinned host, async
   host                              cc_ocsort_update_many: N independent trackers on worker threads, while the GPU
-                                    is already busy with the next batch (two batches in flight)
+                                    is already busy with the next batches
 
 No collective anywhere: cameras are independent.  There is no CPU fallback: the detector is the HIP library.
 """
@@ -59,6 +60,7 @@ class _Slot:
         self.out = torch.empty((n, 300, 6), dtype=torch.float32, device=dev)
         self.host_out = torch.empty((n, 300, 6), dtype=torch.float32).pin_memory()
         self.up, self.done = torch.cuda.Event(), torch.cuda.Event()
+        self.stream = torch.cuda.Stream(dev)                 # orders this slot's upload -> detect -> download
         self.t_submit = 0.0
 
 
@@ -66,7 +68,7 @@ class StreamPipeline:
     """N cameras -> one GPU.  submit(frames) queues upload + detect + download; collect() waits for the oldest batch in
     flight and advances the N trackers.  Keep <= depth batches in flight (run() does)."""
 
-    def __init__(self, model, n_cams: int, frame_hw=(1080, 1920), depth: int = 2, det_thresh: float = 0.25,
+    def __init__(self, model, n_cams: int, frame_hw=(1080, 1920), depth: int = 3, det_thresh: float = 0.25,
                  tracker_kwargs: Optional[dict] = None, n_threads: Optional[int] = None, track: bool = True):
         import torch
         self.torch = torch
@@ -74,6 +76,9 @@ class StreamPipeline:
         self.dev = torch.device("cuda", model.device)
         self.copy_stream, self.compute_stream = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
         self.slots = [_Slot(n_cams, frame_hw[0], frame_hw[1], self.dev) for _ in range(depth)]
+        self.in_flight = hasattr(model, "submit") and depth > 1          # one detector slot per batch in flight
+        if self.in_flight:
+            model.set_in_flight(depth)
         if n_threads is None:
             try:
                 n_threads = len(os.sched_getaffinity(0))
@@ -101,11 +106,16 @@ class StreamPipeline:
                 for i, f in enumerate(frames):
                     s.frames[i].copy_(f, non_blocking=True)
                 s.up.record(self.copy_stream)
-            self.compute_stream.wait_event(s.up)
-        with torch.cuda.stream(self.compute_stream):
-            self.model.detect_batch_device(s.frames, s.out)
+        st = s.stream if self.in_flight else self.compute_stream
+        if frames is not None:
+            st.wait_event(s.up)
+        with torch.cuda.stream(st):
+            if self.in_flight:
+                self.model.wait(self.model.submit(s.frames, s.out))     # ordered after the upload; st then waits for the rows
+            else:
+                self.model.detect_batch_device(s.frames, s.out)
             s.host_out.copy_(s.out, non_blocking=True)
-            s.done.record(self.compute_stream)
+            s.done.record(st)
         self.submitted += 1
 
     def collect(self):
@@ -132,16 +142,17 @@ class StreamPipeline:
         if cameras is None:
             for s in self.slots:                                  # something to detect on
                 s.frames.random_(0, 256)
-        for _ in range(warmup):
+        for _ in range(max(warmup, self.depth)):                  # every slot has built its plan before the clock starts
             self.submit(grab()); self.collect()
         torch.cuda.synchronize(self.dev)
         self.track_s, self.latency, self.n_dets = 0.0, [], 0
         t0 = time.perf_counter()
-        self.submit(grab())
-        for _ in range(n_batches - 1):
+        for _ in range(n_batches):                               # `depth` batches in flight: the oldest is collected when the ring is full
+            if self.submitted - self.collected == self.depth:
+                self.collect()
             self.submit(grab())
+        while self.collected < self.submitted:
             self.collect()
-        self.collect()
         dt = time.perf_counter() - t0
         frames = n_batches * self.n
         nbytes = self.n * self.hw[0] * self.hw[1] * 3

@@ -90,6 +90,31 @@ class YOLOv9:
                                              _lib.ptr(out), 1, C.c_void_p(s)))
         return out
 
+    # -- batches in flight (throughput mode: one GPU serving many cameras) --------------------------
+    def set_in_flight(self, n: int) -> None:
+        """n slots (own stream, arena and graph each): consecutive submit() calls overlap - the last layers of one batch run beside
+        the first layers of the next.  Results are bit-identical to detect_batch_device; n = 1 is the default."""
+        _lib.check(_lib.lib().cc_yolo_set_in_flight(self._h, n))
+        self.in_flight = n
+
+    def submit(self, frames, out) -> int:
+        """Queue one batch (CUDA uint8 / float32 (B,H,W,3) -> `out` (B,300,6) float32 on the device) on the next slot, ordered after
+        the current torch stream; the current stream does NOT wait for the result - wait(ticket) does.  `frames` and `out` must stay
+        alive (and `out` unshared with other submissions in flight) until then."""
+        import torch
+        B, H, W, _ = frames.shape
+        t = C.c_longlong()
+        s = torch.cuda.current_stream(frames.device).cuda_stream
+        _lib.check(_lib.lib().cc_yolo_submit(self._h, _lib.ptr(frames), B, H, W, int(frames.dtype == torch.float32), _lib.ptr(out),
+                                             C.c_void_p(s), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int, host: bool = False) -> None:
+        """Make the current torch stream (host=True: the calling thread) wait for a submission's result."""
+        import torch
+        s = None if host else C.c_void_p(torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream)
+        _lib.check(_lib.lib().cc_yolo_wait(self._h, ticket, s))
+
     # -- parity taps --------------------------------------------------------------------------------
     def get_tensor(self, name: str) -> np.ndarray:
         L = _lib.lib()

@@ -32,6 +32,16 @@ class FakeYolo:
     def detect_batch(self, frames):
         return np.zeros((len(frames), 300, 6), np.float32)
 
+    def set_in_flight(self, n):
+        self.in_flight = n
+
+    def submit(self, frames, out):
+        self.detect_batch_device(frames, out)
+        return 0
+
+    def wait(self, ticket, host=False):
+        pass
+
     def profile(self, iters=3):
         return {"alg_macs_per_step": 1e9, "conv_ms": 1.0, "conv_launches": 1, "pool_ms": 0.0, "decode_ms": 0.0, "nms_ms": 0.0, "stem_ms": 0.0}
 

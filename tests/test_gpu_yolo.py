@@ -13,6 +13,7 @@ Tolerances (BASELINE.json north_star: "box coords/classes within 1e-3"):
     give top-k / NMS real work; its 16-bit end-to-end test is only a guard against gross breakage.
 """
 import ctypes as C
+import contextlib
 import os
 
 import numpy as np
@@ -602,6 +603,49 @@ def test_concurrent_lanes_equal_one_chain(size, res, dtype, shape):
         for det, dec, p3, p5 in runs:
             assert np.array_equal(det, ref[0]) and np.array_equal(dec, ref[1]), label
             assert np.array_equal(p3, ref[2]) and np.array_equal(p5, ref[3]), label
+
+
+@pytest.mark.parametrize("size,res,dtype", [("c", 640, "f16"), ("t", 320, "bf16"), ("s", 320, "f32")])
+def test_batches_in_flight_equal_detect(size, res, dtype):
+    """cc_yolo_set_in_flight / cc_yolo_submit / cc_yolo_wait: batches queued round robin on the handle's slots (own stream, arena and
+    graph each, so consecutive batches overlap on the GPU) give exactly the rows cc_yolo_detect gives for the same frames - for
+    every depth, for batch shapes that change between submissions (a plan per slot and shape), with the wait on a torch stream or
+    on the host, and with cc_yolo_detect calls in between."""
+    import torch
+    from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict
+    sd = conditioned_yolov9_state_dict("c", 1234) if size == "c" else synthetic_yolov9_state_dict(size, 1234)
+    m = _yolo(size, res, sd, dtype)
+    shapes = [(3, res, res), (2, 270, 480), (3, res, res), (1, 360, 640), (2, 270, 480), (3, res, res), (3, res, res)]
+    frames = [torch.from_numpy(noise_frames(20 + i, *shp)).cuda() for i, shp in enumerate(shapes)]
+    ref = [m.detect_batch(f) for f in frames]
+    assert sum(int((r[..., 4] > 0).sum()) for r in ref) > 0
+    for depth in (1, 2, 3, 4):
+        m.set_in_flight(depth)
+        for rnd in range(2):                                   # 0: submissions and waits on a torch side stream, 1: host waits
+            outs = [torch.full((f.shape[0], 300, 6), -1.0, device="cuda") for f in frames]
+            torch.cuda.synchronize()
+            tickets = []
+            with (torch.cuda.stream(torch.cuda.Stream()) if rnd == 0 else contextlib.nullcontext()):
+                for i, f in enumerate(frames):
+                    while len(tickets) - sum(t is None for t in tickets) > depth - 1:      # at most `depth` unwaited submissions
+                        j = next(k for k, t in enumerate(tickets) if t is not None)
+                        m.wait(tickets[j], host=bool(rnd)); tickets[j] = None
+                    tickets.append(m.submit(f, outs[i]))
+                    if i == 3:
+                        assert np.array_equal(m.detect_batch(frames[0]), ref[0])           # the synchronous call between submissions
+                for t in tickets:
+                    if t is not None:
+                        m.wait(t, host=bool(rnd))
+                torch.cuda.current_stream().synchronize()
+            for i in range(len(frames)):
+                assert np.array_equal(outs[i].cpu().numpy(), ref[i]), (depth, rnd, i)
+    with pytest.raises(RuntimeError):
+        m.wait(10 ** 9)                                                                # no such submission
+    with pytest.raises(RuntimeError):
+        m.set_in_flight(0)
+    m.set_in_flight(1)
+    assert np.array_equal(m.detect_batch(frames[1]), ref[1])
+    m.close()
 
 
 _ADOWN_SCRIPT = r"""
