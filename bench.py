@@ -417,7 +417,6 @@ def main() -> None:
         torch.cuda.set_device(local)
 
     sd = synthetic_yolov9_state_dict(args.size, 1234)
-    model = YOLOv9(args.size, args.res, state_dict=sd, dtype=args.dtype, device=local)
     B = args.batch
     fh, fw = args.height or args.res, args.width or args.res
     frames = torch.from_numpy(np.random.default_rng(1 + rank).integers(0, 256, (B, fh, fw, 3), dtype=np.uint8)).to(dev)
@@ -461,9 +460,12 @@ def main() -> None:
             m.set_in_flight(depth)
         return m
 
-    # the headline: K batches through `depth` slots of one handle; next to it the same K batches as back-to-back cc_yolo_detect calls
-    model_p = in_flight_model(args.dtype) if depth > 1 else model
+    # the headline: K batches through `depth` slots of one handle; next to it the same K batches as back-to-back cc_yolo_detect calls.
+    # The in-flight handle goes first: its slots' streams are then the first the process puts to work, i.e. each gets a hardware
+    # queue of its own (streams created later share queues once the runtime's pool is full, and slots sharing a queue do not overlap)
+    model_p = in_flight_model(args.dtype)
     elapsed = timed(model_p, args.steps, args.warmup, depth)
+    model = YOLOv9(args.size, args.res, state_dict=sd, dtype=args.dtype, device=local) if depth > 1 else model_p
     elapsed_one = timed(model, args.steps, args.warmup, 1) if depth > 1 else elapsed
     # What the collective backend actually saw: an all-reduce of ones (= the number of ranks that took part) and every rank's own
     # K-step time, so that the driver's scaling record can check "N ranks over RCCL" against the line instead of trusting --gpus.

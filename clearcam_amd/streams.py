@@ -1,16 +1,17 @@
-"""Many-camera driver: pinned frame rings -> async H2D -> batched letterbox + detect -> async D2H -> OC-SORT per camera.
+"""Many-camera driver: pinned frame bank -> one async H2D per tick -> batched letterbox + detect -> async D2H -> OC-SORT per camera.
 
 The reference runs one process per camera whose loop is `frame -> Tensor(frame) -> jit_infer(yolo) -> .numpy() ->
 tracker.update` (clearcam.py:247-279,583-585): one synchronous copy and one batch-1 inference per frame.  Here one
 process per GPU serves N cameras per step (BASELINE.json configs[3]: 1080p cameras, one camera -> one GPU):
 
-  decode thread / synthetic source  writes frames into a PINNED host ring per camera (no per-frame allocation)
-  copy stream                       N x hipMemcpyAsync ring slot -> slot of the device batch   (overlaps compute)
-  model slots                       letterbox (bit-exact u8 bilinear) + 144 convs + decode + top-300/NMS, one captured graph per slot;
-                                    `depth` batches in flight (YOLOv9.submit: the last layers of a batch overlap the first of the next)
+  decode thread / synthetic source  writes frames into its row of a PINNED bank (ring, N, H, W, 3) shared by the GPU's cameras
+  copy stream                       ONE hipMemcpyAsync per tick, bank slot -> slot of the device batch (57 GB/s against 44 GB/s for N
+                                    per-camera copies; overlaps compute)
+  model stream                      letterbox (bit-exact u8 bilinear) + 144 convs + decode + top-300/NMS, one captured graph;
+                                    in_flight=True: one detector slot per batch in flight instead (YOLOv9.submit)
   copy back                         (N,300,6) float32 -> pinned host, async
   host                              cc_ocsort_update_many: N independent trackers on worker threads, while the GPU
-                                    is already busy with the next batches
+                                    is already busy with the next batches (three in flight: upload, detect, track)
 
 No collective anywhere: cameras are independent.  There is no CPU fallback: the detector is the HIP library.
 """
@@ -29,12 +30,13 @@ class SyntheticCamera:
     """Stand-in for a camera's decode thread (clearcam.py:401-421): a pinned ring of pre-decoded BGR uint8 frames.
     Seeded noise background plus a few moving rectangles so consecutive frames differ."""
 
-    def __init__(self, height: int = 1080, width: int = 1920, seed: int = 0, ring: int = 2, base: Optional[np.ndarray] = None):
+    def __init__(self, height: int = 1080, width: int = 1920, seed: int = 0, ring: int = 2, base: Optional[np.ndarray] = None, storage=None):
         import torch
         rng = np.random.default_rng(seed)
         if base is None:
             base = rng.integers(0, 256, (height, width, 3), dtype=np.uint8)
-        self.frames = torch.empty((ring, height, width, 3), dtype=torch.uint8).pin_memory()
+        # storage: a pinned (ring, H, W, 3) view into a bank shared by all cameras of the GPU (CameraBank), else a ring of its own
+        self.frames = storage if storage is not None else torch.empty((ring, height, width, 3), dtype=torch.uint8).pin_memory()
         view = self.frames.numpy()
         boxes = [(int(rng.integers(0, max(1, height - height // 4))), int(rng.integers(0, max(1, width - width // 6))),
                   max(2, height // int(rng.integers(4, 9))), max(2, width // int(rng.integers(6, 14))),
@@ -53,13 +55,35 @@ class SyntheticCamera:
         return f
 
 
+class CameraBank(list):
+    """The cameras of one GPU writing into ONE pinned buffer (ring, N, H, W, 3): camera i's decode thread owns row i of every ring
+    slot, so the frames of a tick are contiguous and go up as a single copy - 57 GB/s over PCIe gen5 against 44 GB/s for N copies of
+    one 6 MB frame each (MI355X box, profiles/r03s_h2d_rate.txt).  A list of the N SyntheticCamera objects (each still has read())
+    plus read_all()."""
+
+    def __init__(self, n: int, height: int = 1080, width: int = 1920, ring: int = 2, seed: int = 100):
+        import torch
+        base = np.random.default_rng(seed).integers(0, 256, (height, width, 3), dtype=np.uint8)
+        self.bank = torch.empty((ring, n, height, width, 3), dtype=torch.uint8).pin_memory()
+        super().__init__(SyntheticCamera(height, width, seed=i, ring=ring, base=base, storage=self.bank[:, i]) for i in range(n))
+        self.ring, self.t = ring, 0
+
+    def read_all(self):
+        """The next frame of every camera as one pinned (N,H,W,3) uint8 tensor (no copy)."""
+        f = self.bank[self.t % self.ring]
+        self.t += 1
+        for c in self:
+            c.t = self.t
+        return f
+
+
 class _Slot:
     def __init__(self, n, h, w, dev):
         import torch
         self.frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
         self.out = torch.empty((n, 300, 6), dtype=torch.float32, device=dev)
         self.host_out = torch.empty((n, 300, 6), dtype=torch.float32).pin_memory()
-        self.up, self.done = torch.cuda.Event(), torch.cuda.Event()
+        self.ups, self.done = [torch.cuda.Event() for _ in range(8)], torch.cuda.Event()
         self.stream = torch.cuda.Stream(dev)                 # orders this slot's upload -> detect -> download
         self.t_submit = 0.0
 
@@ -69,14 +93,19 @@ class StreamPipeline:
     flight and advances the N trackers.  Keep <= depth batches in flight (run() does)."""
 
     def __init__(self, model, n_cams: int, frame_hw=(1080, 1920), depth: int = 3, det_thresh: float = 0.25,
-                 tracker_kwargs: Optional[dict] = None, n_threads: Optional[int] = None, track: bool = True):
+                 tracker_kwargs: Optional[dict] = None, n_threads: Optional[int] = None, track: bool = True, copy_streams: int = 1,
+                 in_flight: bool = False):
         import torch
         self.torch = torch
         self.model, self.n, self.hw, self.depth = model, n_cams, tuple(frame_hw), depth
         self.dev = torch.device("cuda", model.device)
-        self.copy_stream, self.compute_stream = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self.copy_streams = [torch.cuda.Stream(self.dev) for _ in range(max(1, copy_streams))]
+        self.copy_stream, self.compute_stream = self.copy_streams[0], torch.cuda.Stream(self.dev)
         self.slots = [_Slot(n_cams, frame_hw[0], frame_hw[1], self.dev) for _ in range(depth)]
-        self.in_flight = hasattr(model, "submit") and depth > 1          # one detector slot per batch in flight
+        # Detector slots (YOLOv9.submit: consecutive batches overlap on the GPU) pay when the frames are already in HBM (+6 % at 64 x
+        # 1080p); with PCIe uploads in the loop they cost more upload rate than they gain (7.1-7.4 k frames/s against 8.3 k with one
+        # detector stream, profiles/r03s_streams_ab.txt), so they are opt-in here.
+        self.in_flight = bool(in_flight) and hasattr(model, "submit") and depth > 1
         if self.in_flight:
             model.set_in_flight(depth)
         if n_threads is None:
@@ -102,13 +131,22 @@ class StreamPipeline:
         if frames is not None:
             if len(frames) != self.n:
                 raise ValueError(f"expected {self.n} frames, got {len(frames)}")
-            with torch.cuda.stream(self.copy_stream):
-                for i, f in enumerate(frames):
-                    s.frames[i].copy_(f, non_blocking=True)
-                s.up.record(self.copy_stream)
+            if hasattr(frames, "is_pinned") and frames.dim() == 4:       # one pinned (N,H,W,3) tensor (CameraBank.read_all): a single copy
+                with torch.cuda.stream(self.copy_stream):
+                    s.frames.copy_(frames, non_blocking=True)
+                    s.ups[0].record(self.copy_stream)
+                nup = 1
+            else:
+                nup = len(self.copy_streams)
+                for j, cs in enumerate(self.copy_streams):           # cameras dealt over the copy streams
+                    with torch.cuda.stream(cs):
+                        for i in range(j, self.n, nup):
+                            s.frames[i].copy_(frames[i], non_blocking=True)
+                        s.ups[j].record(cs)
         st = s.stream if self.in_flight else self.compute_stream
         if frames is not None:
-            st.wait_event(s.up)
+            for j in range(nup):
+                st.wait_event(s.ups[j])
         with torch.cuda.stream(st):
             if self.in_flight:
                 self.model.wait(self.model.submit(s.frames, s.out))     # ordered after the upload; st then waits for the rows
@@ -138,7 +176,7 @@ class StreamPipeline:
     def run(self, cameras: Optional[List[SyntheticCamera]], n_batches: int, warmup: int = 2) -> Dict[str, float]:
         """Steady-state loop over n_batches (+warmup) batches; cameras=None benchmarks with frames resident in HBM."""
         torch = self.torch
-        grab = (lambda: [c.read() for c in cameras]) if cameras is not None else (lambda: None)
+        grab = (lambda: None) if cameras is None else cameras.read_all if hasattr(cameras, "read_all") else (lambda: [c.read() for c in cameras])
         if cameras is None:
             for s in self.slots:                                  # something to detect on
                 s.frames.random_(0, 256)
@@ -170,7 +208,10 @@ class StreamPipeline:
             t.close()
 
 
-def make_cameras(n: int, height: int = 1080, width: int = 1920, ring: int = 2, seed: int = 100) -> List[SyntheticCamera]:
+def make_cameras(n: int, height: int = 1080, width: int = 1920, ring: int = 2, seed: int = 100, bank: bool = True) -> List[SyntheticCamera]:
+    """N synthetic cameras; bank=True (default): their rings are rows of one pinned buffer (CameraBank: one upload per tick)."""
+    if bank:
+        return CameraBank(n, height, width, ring, seed)
     base = np.random.default_rng(seed).integers(0, 256, (height, width, 3), dtype=np.uint8)
     return [SyntheticCamera(height, width, seed=i, ring=ring, base=base) for i in range(n)]
 
