@@ -29,9 +29,6 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-# Batches in flight run on streams of their own; the HIP runtime maps streams onto 4 hardware queues unless told otherwise, and two
-# slots that share a queue do not overlap.  Read when the runtime initialises (the first HIP call), so it is set before torch loads.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 FLOP_PER_FRAME_C640 = 2 * 51.068e9
@@ -461,8 +458,8 @@ def main() -> None:
         return m
 
     # the headline: K batches through `depth` slots of one handle; next to it the same K batches as back-to-back cc_yolo_detect calls.
-    # The in-flight handle goes first: its slots' streams are then the first the process puts to work, i.e. each gets a hardware
-    # queue of its own (streams created later share queues once the runtime's pool is full, and slots sharing a queue do not overlap)
+    # (cc_yolo_set_in_flight probes its slots' streams until they really run side by side: the runtime maps streams onto a few
+    # hardware queues and two slots on one queue would not overlap)
     model_p = in_flight_model(args.dtype)
     elapsed = timed(model_p, args.steps, args.warmup, depth)
     model = YOLOv9(args.size, args.res, state_dict=sd, dtype=args.dtype, device=local) if depth > 1 else model_p

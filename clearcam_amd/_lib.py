@@ -60,7 +60,7 @@ def lib() -> C.CDLL:
         "cc_yolo_finalize": [vp],
         "cc_yolo_detect": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_yolo_set_in_flight": [vp, C.c_int],
-        "cc_yolo_submit": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_longlong)],
+        "cc_yolo_submit": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_longlong)],
         "cc_yolo_wait": [vp, C.c_longlong, vp],
         "cc_yolo_get_tensor": [vp, C.c_char_p, vp, i64p, ip],
         "cc_yolo_last_gpu_ms": [vp, fp],

@@ -160,16 +160,17 @@ struct Builder {
 
   int cur_lane = 0;
   // Which independent chains leave the trunk (CLEARCAM_LANES, read per plan): bit 1 = each DDetect level on its own lane (2-4), bit 2 =
-  // the three levels share lane 2, bit 0 = ADown's pooled half on lane 1.  Default: the DDetect levels, for plans of at least 16
-  // network-sized frames - there P3's 3x3 convs fill the CUs the neck's 40x40 / 20x20 launches leave idle (B = 64: 11.39 -> 11.24 ms,
-  // B = 16: 3.75 -> 3.67); a graph with branches costs ~50 us of extra synchronisation per replay, so small plans stay one chain
-  // (B = 8: 2.35 -> 2.39 ms, one frame 1.30 -> 1.35).  ADown's halves gained nothing at any size (both open with a bandwidth-bound
-  // pool).  profiles/r03o_lanes_ab*.txt.  Outputs are bit-identical either way.
+  // the three levels share lane 2, bit 0 = ADown's pooled half on lane 1.  OFF by default.  Measured with nothing else on the GPU:
+  // DDetect lanes B = 64: 11.39 -> 11.24 ms, B = 16: 3.75 -> 3.67 (P3's 3x3 convs fill the CUs the neck's 40x40 / 20x20 launches
+  // leave idle); a graph with branches costs ~50 us per replay (B = 8: 2.35 -> 2.39 ms, one frame 1.30 -> 1.35); ADown's halves gain
+  // nothing (both open with a bandwidth-bound pool); profiles/r03o_lanes_ab*.txt.  But the runtime replays the branches on
+  // internal streams that share its few hardware queues with every other stream of the process, and inside a camera pipeline
+  // (upload, download and caller streams) a branch that lands behind another stream's barrier costs far more than the lanes gain
+  // (64 x 1080p cameras, frames resident: 6.1 k frames/s with lanes against 8.5-9 k without, profiles/r03s_*).  Batches in flight
+  // (cc_yolo_submit, slots on probed queues) are the robust way to fill those CUs.  Outputs are bit-identical either way.
   int lanes_mask() const {
     const char* e = getenv("CLEARCAM_LANES");
-    if (e) return atoi(e);
-    if (!Y->slot_stream.empty()) return 0;                     // batches in flight already fill those CUs with the next batch
-    return (long)P->B * P->Hn * P->Wn >= 16L * 640 * 640 ? 2 : 0;
+    return e ? atoi(e) : 0;
   }
   struct Lane {                                            // scope guard: launches pushed inside run on lane `l`
     Builder& b; int saved;
@@ -970,6 +971,39 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
   CC_API_END
 }
 
+// ~0.2 ms of one wave doing nothing (s_memrealtime ticks at 100 MHz): the probe of streams_overlap
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+
+// Do kernels on streams a and b run side by side?  Both streams idle on entry.  One spin kernel alone, then one on each stream
+// (b's first: if the two share a queue, a's is queued behind it): on different hardware queues the pair takes about one kernel's time.
+static bool streams_overlap(cc_yolo* h, hipStream_t a, hipStream_t b) {
+  const long long ticks = 20000;
+  hipEvent_t e0 = h->ev0, e1 = h->ev1, eb = nullptr;
+  CC_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+  float alone = 0.f, pair = 0.f;
+  for (int rep = 0; rep < 2; ++rep) {                   // the first round also pays for code loading and queue creation
+    CC_HIP(hipEventRecord(e0, a));
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    CC_HIP(hipEventRecord(e1, a));
+    CC_HIP(hipEventSynchronize(e1)); CC_HIP(hipEventElapsedTime(&alone, e0, e1));
+    CC_HIP(hipEventRecord(e0, a));
+    CC_HIP(hipStreamWaitEvent(b, e0, 0));               // b starts no earlier than a's clock
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    CC_HIP(hipEventRecord(eb, b));
+    CC_HIP(hipStreamWaitEvent(a, eb, 0));
+    CC_HIP(hipEventRecord(e1, a));
+    CC_HIP(hipEventSynchronize(e1)); CC_HIP(hipEventElapsedTime(&pair, e0, e1));
+  }
+  hipEventDestroy(eb);
+  CC_HIP(hipGetLastError());
+  if (getenv("CLEARCAM_VERBOSE")) fprintf(stderr, "[clearcam] stream probe: one kernel %.3f ms, one per stream %.3f ms\n", alone, pair);
+  return pair < 1.5f * alone;
+}
+
 // taps and profilers read what the last call left behind: every stream of the handle has to be idle
 static void sync_all(cc_yolo* h) {
   CC_HIP(hipStreamSynchronize(h->stream));
@@ -984,16 +1018,36 @@ int cc_yolo_set_in_flight(cc_yolo* h, int n) {
   h->plans.clear();                                     // plans are built for one depth (lanes on or off) and belong to a slot
   h->last = nullptr;
   while ((int)h->slot_stream.size() > n - 1) { hipStreamDestroy(h->slot_stream.back()); h->slot_stream.pop_back(); }
-  while ((int)h->slot_stream.size() < n - 1) { hipStream_t t; CC_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); h->slot_stream.push_back(t); }
+  // Slots must not share a hardware queue: the runtime maps streams onto a small pool of queues (GPU_MAX_HW_QUEUES, 4 unless the
+  // environment says otherwise, handed out least-used first), packets of one queue run in order, and two slots on one queue do not
+  // overlap at all.  So a new slot's stream is PROBED against the streams it has to run beside (two spin kernels: together they
+  // take one kernel's time on different queues, two on the same) and replaced until it overlaps with all of them; rejected streams
+  // stay alive until the end so that the runtime moves on to another queue.  (Stream priority classes have queue pools of their own
+  // and would separate three slots by construction, but strict priority only fills gaps: 10.7 ms per B = 64 step against 10.1 with
+  // three equal slots.)
+  std::vector<hipStream_t> rejected;
+  while ((int)h->slot_stream.size() < n - 1) {
+    hipStream_t t = nullptr;
+    for (int attempt = 0; attempt < 12; ++attempt) {
+      CC_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
+      bool ok = streams_overlap(h, h->stream, t);
+      for (size_t j = 0; ok && j < h->slot_stream.size(); ++j) ok = streams_overlap(h, h->slot_stream[j], t);
+      if (ok || attempt == 11) break;
+      rejected.push_back(t); t = nullptr;
+    }
+    h->slot_stream.push_back(t);
+  }
+  for (hipStream_t t : rejected) hipStreamDestroy(t);
   while ((int)h->slot_done.size() > n) { hipEventDestroy(h->slot_done.back()); h->slot_done.pop_back(); }
   while ((int)h->slot_done.size() < n) { hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->slot_done.push_back(e); }
   h->submitted = 0;
   CC_API_END
 }
 
-int cc_yolo_submit(cc_yolo* h, const void* frames_dev, int B, int H, int W, int frame_f32, float* out_dev, void* stream, long long* ticket) {
+int cc_yolo_submit(cc_yolo* h, const void* frames, int B, int H, int W, int frame_f32, int frames_on_device, float* out, int out_on_device,
+                   void* stream, long long* ticket) {
   CC_API_BEGIN
-  CC_CHECK(h && frames_dev && out_dev && ticket, "null argument");
+  CC_CHECK(h && frames && out && ticket, "null argument");
   CC_CHECK(h->finalized, "cc_yolo_submit before cc_yolo_finalize");
   CC_CHECK(B > 0 && H > 0 && W > 0, "bad frame shape");
   CC_HIP(hipSetDevice(h->device));
@@ -1005,8 +1059,12 @@ int cc_yolo_submit(cc_yolo* h, const void* frames_dev, int B, int H, int W, int 
     hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CC_HIP(hipEventRecord(e, (hipStream_t)stream)); CC_HIP(hipStreamWaitEvent(s, e, 0)); CC_HIP(hipEventDestroy(e));
   }
-  enqueue_step(h, P, s, frames_dev);
-  CC_HIP(hipMemcpyAsync(out_dev, P->out_dev, (size_t)B * CC_MAX_DET * 6 * 4, hipMemcpyDeviceToDevice, s));
+  // host frames / rows (pinned, or the copies are not asynchronous): upload, detect and download are one in-order chain on the slot's
+  // stream, and the chains of the slots overlap - the upload of one batch runs under the convs of another
+  const void* fdev = frames;
+  if (!frames_on_device) { CC_HIP(hipMemcpyAsync(P->frames_dev, frames, P->frames_bytes, hipMemcpyHostToDevice, s)); fdev = P->frames_dev; }
+  enqueue_step(h, P, s, fdev);
+  CC_HIP(hipMemcpyAsync(out, P->out_dev, (size_t)B * CC_MAX_DET * 6 * 4, out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
   CC_HIP(hipEventRecord(h->slot_done[slot], s));
   h->last = P;
   *ticket = h->submitted++;

@@ -11,7 +11,7 @@ process per GPU serves N cameras per step (BASELINE.json configs[3]: 1080p camer
                                     in_flight=True: one detector slot per batch in flight instead (YOLOv9.submit)
   copy back                         (N,300,6) float32 -> pinned host, async
   host                              cc_ocsort_update_many: N independent trackers on worker threads, while the GPU
-                                    is already busy with the next batches (three in flight: upload, detect, track)
+                                    is already busy with the next batch (two batches in flight)
 
 No collective anywhere: cameras are independent.  There is no CPU fallback: the detector is the HIP library.
 """
@@ -84,7 +84,7 @@ class _Slot:
         self.out = torch.empty((n, 300, 6), dtype=torch.float32, device=dev)
         self.host_out = torch.empty((n, 300, 6), dtype=torch.float32).pin_memory()
         self.ups, self.done = [torch.cuda.Event() for _ in range(8)], torch.cuda.Event()
-        self.stream = torch.cuda.Stream(dev)                 # orders this slot's upload -> detect -> download
+        self.ticket = None                                   # detector-slot submission (in_flight mode)
         self.t_submit = 0.0
 
 
@@ -92,19 +92,25 @@ class StreamPipeline:
     """N cameras -> one GPU.  submit(frames) queues upload + detect + download; collect() waits for the oldest batch in
     flight and advances the N trackers.  Keep <= depth batches in flight (run() does)."""
 
-    def __init__(self, model, n_cams: int, frame_hw=(1080, 1920), depth: int = 3, det_thresh: float = 0.25,
+    def __init__(self, model, n_cams: int, frame_hw=(1080, 1920), depth: int = 2, det_thresh: float = 0.25,
                  tracker_kwargs: Optional[dict] = None, n_threads: Optional[int] = None, track: bool = True, copy_streams: int = 1,
                  in_flight: bool = False):
         import torch
         self.torch = torch
         self.model, self.n, self.hw, self.depth = model, n_cams, tuple(frame_hw), depth
         self.dev = torch.device("cuda", model.device)
-        self.copy_streams = [torch.cuda.Stream(self.dev) for _ in range(max(1, copy_streams))]
+        # high-priority streams take their hardware queue from a pool of their own: the uploads never queue behind a kernel of
+        # some normal-priority stream that happens to share a queue (the runtime maps all streams of a class onto a few queues)
+        self.copy_streams = [torch.cuda.Stream(self.dev, priority=-1) for _ in range(max(1, copy_streams))]
         self.copy_stream, self.compute_stream = self.copy_streams[0], torch.cuda.Stream(self.dev)
         self.slots = [_Slot(n_cams, frame_hw[0], frame_hw[1], self.dev) for _ in range(depth)]
-        # Detector slots (YOLOv9.submit: consecutive batches overlap on the GPU) pay when the frames are already in HBM (+6 % at 64 x
-        # 1080p); with PCIe uploads in the loop they cost more upload rate than they gain (7.1-7.4 k frames/s against 8.3 k with one
-        # detector stream, profiles/r03s_streams_ab.txt), so they are opt-in here.
+        # Defaults = the configuration that measured the same on every run: two batches in flight, one detector stream
+        # (64 x 1080p: 6.9-7.1 k frames/s, 8 x 1080p: 3.9-4.1 k).  in_flight=True gives every batch in flight a detector slot of its
+        # own (YOLOv9.submit with pinned host tensors: upload -> detect -> download as one chain per slot; with depth 3: 8 x 1080p
+        # 4.6 k frames/s, frames resident 6.2 k against 4.4 k; 64 x 1080p frames resident 9.6 k against 9.3 k, but with uploads 5.2 k:
+        # a 398 MB upload under two other batches' kernels drops to 30 GB/s).  depth=3 with one detector stream reached 8.3-8.5 k
+        # frames/s at 64 x 1080p (upload at 52 GB/s beside the detector) on some runs and 5.9 k on others, depending on which
+        # hardware queues the runtime gave the streams - not a default.  profiles/r03s_streams_ab*.txt.
         self.in_flight = bool(in_flight) and hasattr(model, "submit") and depth > 1
         if self.in_flight:
             model.set_in_flight(depth)
@@ -128,30 +134,33 @@ class StreamPipeline:
             raise RuntimeError("too many batches in flight: call collect() first")
         s = self.slots[self.submitted % self.depth]
         s.t_submit = time.perf_counter()
-        if frames is not None:
-            if len(frames) != self.n:
-                raise ValueError(f"expected {self.n} frames, got {len(frames)}")
-            if hasattr(frames, "is_pinned") and frames.dim() == 4:       # one pinned (N,H,W,3) tensor (CameraBank.read_all): a single copy
-                with torch.cuda.stream(self.copy_stream):
-                    s.frames.copy_(frames, non_blocking=True)
-                    s.ups[0].record(self.copy_stream)
-                nup = 1
-            else:
-                nup = len(self.copy_streams)
-                for j, cs in enumerate(self.copy_streams):           # cameras dealt over the copy streams
-                    with torch.cuda.stream(cs):
-                        for i in range(j, self.n, nup):
-                            s.frames[i].copy_(frames[i], non_blocking=True)
-                        s.ups[j].record(cs)
-        st = s.stream if self.in_flight else self.compute_stream
-        if frames is not None:
-            for j in range(nup):
-                st.wait_event(s.ups[j])
+        if frames is not None and len(frames) != self.n:
+            raise ValueError(f"expected {self.n} frames, got {len(frames)}")
+        whole = frames is not None and hasattr(frames, "is_pinned") and frames.dim() == 4      # one pinned (N,H,W,3) tensor (CameraBank.read_all)
+        if self.in_flight and (frames is None or whole):
+            # one in-order chain on the detector slot's own stream: upload -> detect -> download; the chains of the slots overlap
+            s.ticket = self.model.submit(s.frames if frames is None else frames, s.host_out)
+            self.submitted += 1
+            return
+        s.ticket = None
+        nup = 0
+        if whole:                                                # a single copy of the whole tick
+            with torch.cuda.stream(self.copy_stream):
+                s.frames.copy_(frames, non_blocking=True)
+                s.ups[0].record(self.copy_stream)
+            nup = 1
+        elif frames is not None:
+            nup = len(self.copy_streams)
+            for j, cs in enumerate(self.copy_streams):           # one copy per camera, dealt over the copy streams
+                with torch.cuda.stream(cs):
+                    for i in range(j, self.n, nup):
+                        s.frames[i].copy_(frames[i], non_blocking=True)
+                    s.ups[j].record(cs)
+        st = self.compute_stream
+        for j in range(nup):
+            st.wait_event(s.ups[j])
         with torch.cuda.stream(st):
-            if self.in_flight:
-                self.model.wait(self.model.submit(s.frames, s.out))     # ordered after the upload; st then waits for the rows
-            else:
-                self.model.detect_batch_device(s.frames, s.out)
+            self.model.detect_batch_device(s.frames, s.out)
             s.host_out.copy_(s.out, non_blocking=True)
             s.done.record(st)
         self.submitted += 1
@@ -161,7 +170,10 @@ class StreamPipeline:
         if self.collected >= self.submitted:
             raise RuntimeError("nothing in flight")
         s = self.slots[self.collected % self.depth]
-        s.done.synchronize()
+        if s.ticket is not None:
+            self.model.wait(s.ticket, host=True)
+        else:
+            s.done.synchronize()
         preds = s.host_out.numpy()
         rows = None
         self.n_dets += int((preds[..., 4] > np.float32(self.det_thresh)).sum())

@@ -98,15 +98,20 @@ class YOLOv9:
         self.in_flight = n
 
     def submit(self, frames, out) -> int:
-        """Queue one batch (CUDA uint8 / float32 (B,H,W,3) -> `out` (B,300,6) float32 on the device) on the next slot, ordered after
-        the current torch stream; the current stream does NOT wait for the result - wait(ticket) does.  `frames` and `out` must stay
-        alive (and `out` unshared with other submissions in flight) until then."""
+        """Queue one batch on the next slot: `frames` (B,H,W,3) uint8 / float32 and `out` (B,300,6) float32 are torch tensors, each
+        either on the device or in PINNED host memory (then the slot's stream also carries the upload / download, which overlap the
+        other slots' kernels).  Device frames are taken as ready on the current torch stream, which does NOT wait for the result -
+        wait(ticket) does.  `frames` and `out` must stay alive (and `out` unshared with other submissions in flight) until then."""
         import torch
         B, H, W, _ = frames.shape
+        if not frames.is_contiguous() or not out.is_contiguous():
+            raise ValueError("frames and out must be contiguous")
+        if (not frames.is_cuda and not frames.is_pinned()) or (not out.is_cuda and not out.is_pinned()):
+            raise ValueError("host tensors handed to submit() must be pinned")
         t = C.c_longlong()
-        s = torch.cuda.current_stream(frames.device).cuda_stream
-        _lib.check(_lib.lib().cc_yolo_submit(self._h, _lib.ptr(frames), B, H, W, int(frames.dtype == torch.float32), _lib.ptr(out),
-                                             C.c_void_p(s), C.byref(t)))
+        s = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream if frames.is_cuda else 0
+        _lib.check(_lib.lib().cc_yolo_submit(self._h, _lib.ptr(frames), B, H, W, int(frames.dtype == torch.float32), int(frames.is_cuda),
+                                             _lib.ptr(out), int(out.is_cuda), C.c_void_p(s), C.byref(t)))
         return t.value
 
     def wait(self, ticket: int, host: bool = False) -> None:

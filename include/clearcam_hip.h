@@ -50,14 +50,17 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
                    int frames_on_device, float* out, int out_on_device, void* stream);
 /* Batches in flight - throughput mode for a GPU that serves many cameras (no counterpart in the reference, whose loop is one
  * synchronous batch-1 call per frame, clearcam.py:583).  cc_yolo_set_in_flight(h, n) gives the handle n slots (1..8, default 1), each
- * with its own stream, tensor arena and captured graph; cc_yolo_submit runs one batch on the next slot (round robin), ordered after
- * `stream` (where the caller produced the device frames) but WITHOUT making `stream` wait for the result, so the next submission's
- * first layers overlap this one's last; cc_yolo_wait(h, ticket, stream) makes `stream` (NULL: the host) wait until that
- * submission's (B,300,6) rows are in out_dev.  Results are bit-identical to cc_yolo_detect.  frames_dev must stay valid until the
- * submission has completed; out_dev buffers of submissions in flight must be distinct.  Changing the depth drops the cached plans. */
+ * with its own stream, tensor arena and captured graph (the streams are probed until kernels on them really run side by side);
+ * cc_yolo_submit runs one batch on the next slot (round robin), ordered after `stream` (where the caller produced device frames;
+ * may be NULL) but WITHOUT making `stream` wait for the result, so the next submission's first layers - and its upload - overlap
+ * this one's last; cc_yolo_wait(h, ticket, stream) makes `stream` (NULL: the calling thread) wait until that submission's
+ * (B,300,6) rows are in `out`.  frames / out may be host pointers (frames_on_device / out_on_device = 0; pinned memory, or the copies
+ * are not asynchronous): upload, detect and download then form one in-order chain on the slot's stream.  Results are bit-identical
+ * to cc_yolo_detect.  `frames` must stay valid until the submission has completed; `out` buffers of submissions in flight must be
+ * distinct.  Changing the depth drops the cached plans. */
 int cc_yolo_set_in_flight(cc_yolo* h, int n);
-int cc_yolo_submit(cc_yolo* h, const void* frames_dev, int B, int H, int W, int frame_f32, float* out_dev, void* stream,
-                   long long* ticket);
+int cc_yolo_submit(cc_yolo* h, const void* frames, int B, int H, int W, int frame_f32, int frames_on_device, float* out,
+                   int out_on_device, void* stream, long long* ticket);
 int cc_yolo_wait(cc_yolo* h, long long ticket, void* stream);
 /* Parity taps: copy a named intermediate of the LAST detect call to host float32.
  * names: "input" (B,Hn,Wn,3) | "p3","p4","p5" (B,H,W,C) | "raw0","raw1","raw2" (B,H,W,144) |

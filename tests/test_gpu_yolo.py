@@ -621,12 +621,16 @@ def test_batches_in_flight_equal_detect(size, res, dtype):
     assert sum(int((r[..., 4] > 0).sum()) for r in ref) > 0
     for depth in (1, 2, 3, 4):
         m.set_in_flight(depth)
-        for rnd in range(2):                                   # 0: submissions and waits on a torch side stream, 1: host waits
-            outs = [torch.full((f.shape[0], 300, 6), -1.0, device="cuda") for f in frames]
+        for rnd in range(3):                                   # 0: submissions and waits on a torch side stream, 1: host waits,
+            host = rnd == 2                                     # 2: pinned host frames and rows (upload and download on the slot's stream)
+            outs = [torch.full((f.shape[0], 300, 6), -1.0, device="cpu" if host else "cuda") for f in frames]
+            if host:
+                outs = [o.pin_memory() for o in outs]
+            src = [f.cpu().pin_memory() for f in frames] if host else frames
             torch.cuda.synchronize()
             tickets = []
             with (torch.cuda.stream(torch.cuda.Stream()) if rnd == 0 else contextlib.nullcontext()):
-                for i, f in enumerate(frames):
+                for i, f in enumerate(src):
                     while len(tickets) - sum(t is None for t in tickets) > depth - 1:      # at most `depth` unwaited submissions
                         j = next(k for k, t in enumerate(tickets) if t is not None)
                         m.wait(tickets[j], host=bool(rnd)); tickets[j] = None
@@ -639,6 +643,8 @@ def test_batches_in_flight_equal_detect(size, res, dtype):
                 torch.cuda.current_stream().synchronize()
             for i in range(len(frames)):
                 assert np.array_equal(outs[i].cpu().numpy(), ref[i]), (depth, rnd, i)
+    with pytest.raises(ValueError):
+        m.submit(frames[0].cpu(), torch.empty(3, 300, 6).pin_memory())                 # pageable host frames
     with pytest.raises(RuntimeError):
         m.wait(10 ** 9)                                                                # no such submission
     with pytest.raises(RuntimeError):
