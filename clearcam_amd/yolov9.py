@@ -100,15 +100,23 @@ class YOLOv9:
     def submit(self, frames, out) -> int:
         """Queue one batch on the next slot: `frames` (B,H,W,3) uint8 / float32 and `out` (B,300,6) float32 are torch tensors, each
         either on the device or in PINNED host memory (then the slot's stream also carries the upload / download, which overlap the
-        other slots' kernels).  Device frames are taken as ready on the current torch stream, which does NOT wait for the result -
+        other slots' kernels); numpy arrays are taken as pageable host memory (correct, but the runtime stages such copies and the
+        call may block).  Device frames are taken as ready on the current torch stream, which does NOT wait for the result -
         wait(ticket) does.  `frames` and `out` must stay alive (and `out` unshared with other submissions in flight) until then."""
-        import torch
         B, H, W, _ = frames.shape
+        t = C.c_longlong()
+        if isinstance(frames, np.ndarray) or isinstance(out, np.ndarray):
+            if not (isinstance(frames, np.ndarray) and isinstance(out, np.ndarray)):
+                raise TypeError("frames and out must both be torch tensors or both numpy arrays")
+            if not frames.flags.c_contiguous or not out.flags.c_contiguous or out.dtype != np.float32 or frames.dtype not in (np.uint8, np.float32):
+                raise ValueError("frames: C-contiguous uint8 / float32, out: C-contiguous float32")
+            _lib.check(_lib.lib().cc_yolo_submit(self._h, _lib.ptr(frames), B, H, W, int(frames.dtype == np.float32), 0, _lib.ptr(out), 0, None, C.byref(t)))
+            return t.value
+        import torch
         if not frames.is_contiguous() or not out.is_contiguous():
             raise ValueError("frames and out must be contiguous")
         if (not frames.is_cuda and not frames.is_pinned()) or (not out.is_cuda and not out.is_pinned()):
             raise ValueError("host tensors handed to submit() must be pinned")
-        t = C.c_longlong()
         s = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream if frames.is_cuda else 0
         _lib.check(_lib.lib().cc_yolo_submit(self._h, _lib.ptr(frames), B, H, W, int(frames.dtype == torch.float32), int(frames.is_cuda),
                                              _lib.ptr(out), int(out.is_cuda), C.c_void_p(s), C.byref(t)))
