@@ -182,6 +182,25 @@ def clip_side_metrics(device_index: int, dev) -> dict:
     out["seconds_per_10k_crops"] = round(10000 / r, 3)
     # the reference's own speed test sweeps the batch size (test/test_clip_speed.py:8-15: bs = 1, 2, 4, ... 128)
     out["image_embeds_per_sec_by_batch"] = {str(b): round(rate(b, 8 if b <= 16 else 4), 1) for b in (1, 2, 4, 8, 16, 32, 64, 128)}
+    # ... and with three small batches in flight (cc_clip_submit_image: slots with their own streams; the reference encodes one crop
+    # per call, so many cameras' crops arrive as many small batches)
+    try:
+        m.set_in_flight(3)
+        def rate3(B, reps):
+            x = torch.rand(B, 3, 224, 224, device=dev) * 2 - 1
+            embs = [torch.empty(B, 768, device=dev) for _ in range(3)]
+            for k in range(3):
+                m.submit_image(x, embs[k])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(reps):
+                m.submit_image(x, embs[k % 3])
+            torch.cuda.synchronize()
+            return B / ((time.perf_counter() - t0) / reps)
+        out["image_embeds_per_sec_by_batch_3_in_flight"] = {str(b): round(rate3(b, 24 if b <= 16 else 9), 1) for b in (1, 2, 4, 8, 16, 32, 64)}
+        m.set_in_flight(1)
+    except Exception as exc:                     # noqa: BLE001  a side metric
+        out["image_embeds_per_sec_by_batch_3_in_flight"] = f"error: {type(exc).__name__}: {exc}"
     toks = np.zeros((64, 77), np.int32)
     toks[:, 0] = 49406
     toks[:, 1:5] = [9606, 325, 275, 271]

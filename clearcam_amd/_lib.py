@@ -14,6 +14,7 @@ SYMBOLS = [
     "cc_yolo_get_tensor",
     "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_profile_graph", "cc_yolo_destroy", "cc_conv2d_nhwc", "cc_conv_bench", "cc_dev_set",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
+    "cc_clip_set_in_flight", "cc_clip_submit_image", "cc_clip_wait",
     "cc_clip_last_gpu_ms", "cc_clip_destroy", "cc_crop_preprocess", "cc_cv_resize_linear_u8", "cc_cv_warp_affine_u8",
     "cc_blaze_create", "cc_blaze_load", "cc_blaze_finalize", "cc_blaze_detect", "cc_blaze_destroy",
     "cc_face_create", "cc_face_load", "cc_face_finalize", "cc_face_embed", "cc_face_destroy",
@@ -75,6 +76,9 @@ def lib() -> C.CDLL:
         "cc_clip_finalize": [vp],
         "cc_clip_encode_image": [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_clip_encode_text": [vp, vp, C.c_int, vp, C.c_int, vp],
+        "cc_clip_set_in_flight": [vp, C.c_int],
+        "cc_clip_submit_image": [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_longlong)],
+        "cc_clip_wait": [vp, C.c_longlong, vp],
         "cc_clip_last_gpu_ms": [vp, fp],
         "cc_crop_preprocess": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_cv_resize_linear_u8": [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int],

@@ -54,8 +54,13 @@ struct cc_clip {
   // text tower
   float *tok_emb = nullptr, *tpos = nullptr; Norm ln_final; Lin tproj;
   std::vector<Block> tblocks;
-  PlanCache<int, CPlan> img_plans, txt_plans;
+  PlanCache<int, CPlan> img_plans, txt_plans;             // key: batch size | slot << 24
   bool timed = false;
+  // batches in flight (cc_clip_submit_image / cc_clip_wait), as cc_yolo's: slot i > 0 has its own stream and plans
+  std::vector<hipStream_t> slot_stream;
+  std::vector<hipEvent_t> slot_done;
+  long long submitted = 0;
+  hipStream_t stream_of_slot(int i) const { return i == 0 ? stream : slot_stream[i - 1]; }
 };
 
 namespace {
@@ -160,8 +165,10 @@ void capture(cc_clip* h, CPlan* P) {
   CC_HIP(hipGraphDestroy(graph));
 }
 
-CPlan* image_plan(cc_clip* h, int B) {
-  if (CPlan* hit = h->img_plans.find(B)) return hit;
+CPlan* image_plan(cc_clip* h, int B, int slot = 0) {
+  CC_CHECK(B < (1 << 24), "batch too large");
+  const int key = B | slot << 24;
+  if (CPlan* hit = h->img_plans.find(key)) return hit;
   const cc_clip_config& c = h->cfg;
   std::unique_ptr<CPlan> P(new CPlan()); P->B = B;
   const int g = c.image_size / c.patch, L = g * g + 1, D = c.v_width; const size_t es = dtype_size(h->dtype);
@@ -179,7 +186,7 @@ CPlan* image_plan(cc_clip* h, int B) {
   gemm(P.get(), pooled, B, h->proj, P->out_dev, 1, 0, nullptr);
   COp nm{}; nm.kind = 6; nm.nm = NormP{P->out_dev, B, c.embed, 1e-8f}; P->ops.push_back(nm);
   capture(h, P.get());
-  return h->img_plans.insert(B, std::move(P), h->stream);
+  return h->img_plans.insert(key, std::move(P), h->stream, [&](CPlan*) { for (hipStream_t t : h->slot_stream) hipStreamSynchronize(t); });
 }
 
 CPlan* text_plan(cc_clip* h, int B) {
@@ -309,6 +316,56 @@ int cc_clip_encode_image(cc_clip* h, const float* x, int B, int x_on_device, flo
   CC_API_END
 }
 
+// Batches in flight for the image tower, the contract of cc_yolo_set_in_flight / cc_yolo_submit / cc_yolo_wait (include/clearcam_hip.h).
+// What it buys depends on the batch: a 255-image batch fills the chip by itself (its GEMMs have > 2000 tiles: 48 ms with one, two or
+// three in flight), small batches do not (the reference encodes one crop per call, models/objects.py:356-363).
+int cc_clip_set_in_flight(cc_clip* h, int n) {
+  CC_API_BEGIN
+  CC_CHECK(h && n >= 1 && n <= 8, "in-flight depth must be 1..8");
+  CC_HIP(hipSetDevice(h->device));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  for (hipStream_t t : h->slot_stream) CC_HIP(hipStreamSynchronize(t));
+  while ((int)h->slot_stream.size() > n - 1) { hipStreamDestroy(h->slot_stream.back()); h->slot_stream.pop_back(); }
+  grow_slot_streams(h->stream, h->slot_stream, n - 1);
+  while ((int)h->slot_done.size() > n) { hipEventDestroy(h->slot_done.back()); h->slot_done.pop_back(); }
+  while ((int)h->slot_done.size() < n) { hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->slot_done.push_back(e); }
+  h->submitted = 0;
+  CC_API_END
+}
+
+int cc_clip_submit_image(cc_clip* h, const float* x, int B, int x_on_device, float* out, int out_on_device, void* stream, long long* ticket) {
+  CC_API_BEGIN
+  CC_CHECK(h && x && out && ticket && B > 0, "bad argument");
+  CC_CHECK(h->finalized && h->has_image, "image tower not loaded");
+  CC_HIP(hipSetDevice(h->device));
+  if (h->slot_done.empty()) { hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->slot_done.push_back(e); }
+  const int depth = (int)h->slot_stream.size() + 1, slot = (int)(h->submitted % depth);
+  CPlan* P = image_plan(h, B, slot);
+  hipStream_t s = h->stream_of_slot(slot);
+  if (stream) {   // x is ready on the caller's stream; that stream does not wait for the result (cc_clip_wait does)
+    hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CC_HIP(hipEventRecord(e, (hipStream_t)stream)); CC_HIP(hipStreamWaitEvent(s, e, 0)); CC_HIP(hipEventDestroy(e));
+  }
+  const size_t nb = (size_t)B * 3 * h->cfg.image_size * h->cfg.image_size * 4;
+  CC_HIP(hipMemcpyAsync(P->in_dev, x, nb, x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  CC_HIP(hipGraphLaunch(P->exec, s));
+  CC_HIP(hipMemcpyAsync(out, P->out_dev, (size_t)B * h->cfg.embed * 4, out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  CC_HIP(hipEventRecord(h->slot_done[slot], s));
+  *ticket = h->submitted++;
+  CC_API_END
+}
+
+int cc_clip_wait(cc_clip* h, long long ticket, void* stream) {
+  CC_API_BEGIN
+  CC_CHECK(h, "null handle");
+  CC_CHECK(ticket >= 0 && ticket < h->submitted, "no such submission");
+  CC_HIP(hipSetDevice(h->device));
+  hipEvent_t e = h->slot_done[(int)(ticket % ((long long)h->slot_stream.size() + 1))];   // a later submission of the slot finishes after this one
+  if (stream) CC_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+  else CC_HIP(hipEventSynchronize(e));
+  CC_API_END
+}
+
 int cc_clip_encode_text(cc_clip* h, const int32_t* tokens, int B, float* out, int out_on_device, void* stream) {
   CC_API_BEGIN
   CC_CHECK(h && tokens && out && B > 0, "bad argument");
@@ -350,7 +407,10 @@ void cc_clip_destroy(cc_clip* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  for (hipStream_t t : h->slot_stream) hipStreamSynchronize(t);
   h->img_plans.clear(); h->txt_plans.clear();
+  for (hipStream_t t : h->slot_stream) hipStreamDestroy(t);
+  for (hipEvent_t e : h->slot_done) hipEventDestroy(e);
   for (void* p : h->wallocs) hipFree(p);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);

@@ -111,6 +111,9 @@ struct HeadTailP {
 };
 bool head_tail_supported(int dt, int ch);
 void launch_head_tail(int dt, const HeadTailP& p, hipStream_t stream);
+// batches in flight (yolo.hip): streams for the extra slots of a handle, probed until kernels on them overlap with `base` and each other
+bool streams_overlap(hipStream_t a, hipStream_t b);
+void grow_slot_streams(hipStream_t base, std::vector<hipStream_t>& slots, int n_extra);
 
 struct NmsP {                 // top-300 + mask NMS + scale_boxes: detection/yolov9.py:406-458
   const float* det; int B, A;

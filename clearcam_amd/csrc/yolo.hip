@@ -847,6 +847,66 @@ static Plan* get_plan(cc_yolo* Y, int B, int H, int W, int frame_f32, int slot =
 
 }  // namespace cc
 
+namespace cc {
+
+// ~0.2 ms of one wave doing nothing (s_memrealtime ticks at 100 MHz): the probe of streams_overlap
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+
+// Do kernels on streams a and b run side by side?  Both streams idle on entry.  One spin kernel alone, then one on each stream
+// (b's first: if the two share a queue, a's is queued behind it): on different hardware queues the pair takes about one kernel's time.
+bool streams_overlap(hipStream_t a, hipStream_t b) {
+  const long long ticks = 20000;
+  hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+  CC_HIP(hipEventCreate(&e0)); CC_HIP(hipEventCreate(&e1));
+  CC_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+  float alone = 0.f, pair = 0.f;
+  for (int rep = 0; rep < 2; ++rep) {                   // the first round also pays for code loading and queue creation
+    CC_HIP(hipEventRecord(e0, a));
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    CC_HIP(hipEventRecord(e1, a));
+    CC_HIP(hipEventSynchronize(e1)); CC_HIP(hipEventElapsedTime(&alone, e0, e1));
+    CC_HIP(hipEventRecord(e0, a));
+    CC_HIP(hipStreamWaitEvent(b, e0, 0));               // b starts no earlier than a's clock
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    CC_HIP(hipEventRecord(eb, b));
+    CC_HIP(hipStreamWaitEvent(a, eb, 0));
+    CC_HIP(hipEventRecord(e1, a));
+    CC_HIP(hipEventSynchronize(e1)); CC_HIP(hipEventElapsedTime(&pair, e0, e1));
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(eb);
+  CC_HIP(hipGetLastError());
+  if (getenv("CLEARCAM_VERBOSE")) fprintf(stderr, "[clearcam] stream probe: one kernel %.3f ms, one per stream %.3f ms\n", alone, pair);
+  return pair < 1.5f * alone;
+}
+
+// Slots of a handle (batches in flight) must not share a hardware queue: the runtime maps streams onto a small pool of queues
+// (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise, handed out least-used first), packets of one queue run in order, and
+// two slots on one queue do not overlap at all.  So a new slot's stream is PROBED against the streams it has to run beside and
+// replaced until it overlaps with all of them; rejected streams stay alive until the end so that the runtime moves on to another
+// queue.  (Stream priority classes have queue pools of their own and would separate three slots by construction, but strict
+// priority only fills gaps: 10.7 ms per B = 64 detect step against 10.1 with three equal slots.)
+void grow_slot_streams(hipStream_t base, std::vector<hipStream_t>& slots, int n_extra) {
+  std::vector<hipStream_t> rejected;
+  while ((int)slots.size() < n_extra) {
+    hipStream_t t = nullptr;
+    for (int attempt = 0; attempt < 12; ++attempt) {
+      CC_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
+      bool ok = streams_overlap(base, t);
+      for (size_t j = 0; ok && j < slots.size(); ++j) ok = streams_overlap(slots[j], t);
+      if (ok || attempt == 11) break;
+      rejected.push_back(t); t = nullptr;
+    }
+    slots.push_back(t);
+  }
+  for (hipStream_t t : rejected) hipStreamDestroy(t);
+}
+
+}  // namespace cc
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -971,39 +1031,6 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
   CC_API_END
 }
 
-// ~0.2 ms of one wave doing nothing (s_memrealtime ticks at 100 MHz): the probe of streams_overlap
-__global__ void spin_kernel(long long ticks) {
-  const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) {}
-}
-
-// Do kernels on streams a and b run side by side?  Both streams idle on entry.  One spin kernel alone, then one on each stream
-// (b's first: if the two share a queue, a's is queued behind it): on different hardware queues the pair takes about one kernel's time.
-static bool streams_overlap(cc_yolo* h, hipStream_t a, hipStream_t b) {
-  const long long ticks = 20000;
-  hipEvent_t e0 = h->ev0, e1 = h->ev1, eb = nullptr;
-  CC_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
-  float alone = 0.f, pair = 0.f;
-  for (int rep = 0; rep < 2; ++rep) {                   // the first round also pays for code loading and queue creation
-    CC_HIP(hipEventRecord(e0, a));
-    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
-    CC_HIP(hipEventRecord(e1, a));
-    CC_HIP(hipEventSynchronize(e1)); CC_HIP(hipEventElapsedTime(&alone, e0, e1));
-    CC_HIP(hipEventRecord(e0, a));
-    CC_HIP(hipStreamWaitEvent(b, e0, 0));               // b starts no earlier than a's clock
-    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks);
-    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
-    CC_HIP(hipEventRecord(eb, b));
-    CC_HIP(hipStreamWaitEvent(a, eb, 0));
-    CC_HIP(hipEventRecord(e1, a));
-    CC_HIP(hipEventSynchronize(e1)); CC_HIP(hipEventElapsedTime(&pair, e0, e1));
-  }
-  hipEventDestroy(eb);
-  CC_HIP(hipGetLastError());
-  if (getenv("CLEARCAM_VERBOSE")) fprintf(stderr, "[clearcam] stream probe: one kernel %.3f ms, one per stream %.3f ms\n", alone, pair);
-  return pair < 1.5f * alone;
-}
-
 // taps and profilers read what the last call left behind: every stream of the handle has to be idle
 static void sync_all(cc_yolo* h) {
   CC_HIP(hipStreamSynchronize(h->stream));
@@ -1018,26 +1045,7 @@ int cc_yolo_set_in_flight(cc_yolo* h, int n) {
   h->plans.clear();                                     // plans are built for one depth (lanes on or off) and belong to a slot
   h->last = nullptr;
   while ((int)h->slot_stream.size() > n - 1) { hipStreamDestroy(h->slot_stream.back()); h->slot_stream.pop_back(); }
-  // Slots must not share a hardware queue: the runtime maps streams onto a small pool of queues (GPU_MAX_HW_QUEUES, 4 unless the
-  // environment says otherwise, handed out least-used first), packets of one queue run in order, and two slots on one queue do not
-  // overlap at all.  So a new slot's stream is PROBED against the streams it has to run beside (two spin kernels: together they
-  // take one kernel's time on different queues, two on the same) and replaced until it overlaps with all of them; rejected streams
-  // stay alive until the end so that the runtime moves on to another queue.  (Stream priority classes have queue pools of their own
-  // and would separate three slots by construction, but strict priority only fills gaps: 10.7 ms per B = 64 step against 10.1 with
-  // three equal slots.)
-  std::vector<hipStream_t> rejected;
-  while ((int)h->slot_stream.size() < n - 1) {
-    hipStream_t t = nullptr;
-    for (int attempt = 0; attempt < 12; ++attempt) {
-      CC_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
-      bool ok = streams_overlap(h, h->stream, t);
-      for (size_t j = 0; ok && j < h->slot_stream.size(); ++j) ok = streams_overlap(h, h->slot_stream[j], t);
-      if (ok || attempt == 11) break;
-      rejected.push_back(t); t = nullptr;
-    }
-    h->slot_stream.push_back(t);
-  }
-  for (hipStream_t t : rejected) hipStreamDestroy(t);
+  grow_slot_streams(h->stream, h->slot_stream, n - 1);      // probed: kernels on any two of them really run side by side
   while ((int)h->slot_done.size() > n) { hipEventDestroy(h->slot_done.back()); h->slot_done.pop_back(); }
   while ((int)h->slot_done.size() < n) { hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->slot_done.push_back(e); }
   h->submitted = 0;

@@ -82,6 +82,31 @@ class OpenCLIP:
         _lib.check(_lib.lib().cc_clip_encode_image(self._h, _lib.ptr(x), x.shape[0], 1, _lib.ptr(out), 1, C.c_void_p(s)))
         return out
 
+    # -- batches in flight (many small batches: the reference encodes one crop per call, :356-363) -----------------------------------
+    def set_in_flight(self, n: int) -> None:
+        """n slots (own stream, buffers and graph each) for submit_image(); results are bit-identical to precompute_embedding."""
+        _lib.check(_lib.lib().cc_clip_set_in_flight(self._h, n))
+
+    def submit_image(self, x, out) -> int:
+        """Queue one (B,3,224,224) float32 batch -> `out` (B,768) float32 on the next slot; CUDA or PINNED-host torch tensors.
+        Device input is taken as ready on the current torch stream, which does not wait for the result - wait(ticket) does."""
+        import torch
+        if not x.is_contiguous() or not out.is_contiguous() or x.dtype != torch.float32 or out.dtype != torch.float32:
+            raise ValueError("x and out must be contiguous float32 tensors")
+        if (not x.is_cuda and not x.is_pinned()) or (not out.is_cuda and not out.is_pinned()):
+            raise ValueError("host tensors handed to submit_image() must be pinned")
+        t = C.c_longlong()
+        s = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
+        _lib.check(_lib.lib().cc_clip_submit_image(self._h, _lib.ptr(x), x.shape[0], int(x.is_cuda), _lib.ptr(out), int(out.is_cuda),
+                                                   C.c_void_p(s), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int, host: bool = False) -> None:
+        """Make the current torch stream (host=True: the calling thread) wait for a submission's embeddings."""
+        import torch
+        s = None if host else C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().cc_clip_wait(self._h, ticket, s))
+
     def encode_tokens(self, tokens) -> np.ndarray:
         """Batch form of ``encode_text`` (:145-186): (B,77) int -> (B,768) float32."""
         t = np.ascontiguousarray(as_numpy(tokens), dtype=np.int32)

@@ -118,6 +118,12 @@ int cc_clip_encode_image(cc_clip* h, const float* x, int B, int x_on_device, flo
 /* encode_text: tokens (B,t_ctx) int32 (SOT ... EOT, zero padded) -> out (B,embed) float32 unit-norm.
  * The reference only ever passes B=1 and picks row argmax(tokens) (= EOT) of batch 0. */
 int cc_clip_encode_text(cc_clip* h, const int32_t* tokens, int B, float* out, int out_on_device, void* stream);
+/* Batches in flight for the image tower: the contract of cc_yolo_set_in_flight / cc_yolo_submit / cc_yolo_wait above.  Pays for
+ * small batches (the reference encodes one crop per call, models/objects.py:356-363); a 255-image batch fills the GPU by itself. */
+int cc_clip_set_in_flight(cc_clip* h, int n);
+int cc_clip_submit_image(cc_clip* h, const float* x, int B, int x_on_device, float* out, int out_on_device, void* stream,
+                         long long* ticket);
+int cc_clip_wait(cc_clip* h, long long ticket, void* stream);
 int cc_clip_last_gpu_ms(cc_clip* h, float* ms);
 void cc_clip_destroy(cc_clip* h);
 

@@ -408,3 +408,34 @@ print("OK")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_clip_batches_in_flight_equal_encode():
+    """cc_clip_set_in_flight / cc_clip_submit_image / cc_clip_wait: image batches queued round robin on the handle's slots give
+    exactly the embeddings precompute_embedding gives - every depth, batch sizes changing between submissions, device and pinned
+    host tensors."""
+    import torch
+    from clearcam_amd.arch import CLIP_B32
+    from clearcam_amd.objects import OpenCLIP
+    from clearcam_amd.weights import synthetic_clip_state_dict
+    m = OpenCLIP(state_dict=synthetic_clip_state_dict(CLIP_B32, 7), arch=CLIP_B32, dtype="bf16", device=0)
+    rng = np.random.default_rng(3)
+    xs = [(rng.random((b, 3, 224, 224), dtype=np.float32) * 2 - 1) for b in (1, 3, 1, 8, 2, 3, 1)]
+    ref = [m.precompute_embedding(x).numpy() for x in xs]
+    assert all(np.isfinite(r).all() and abs(np.linalg.norm(r, axis=1) - 1).max() < 1e-4 for r in ref)
+    for depth in (1, 2, 3):
+        m.set_in_flight(depth)
+        for host in (False, True):
+            src = [torch.from_numpy(x).pin_memory() if host else torch.from_numpy(x).cuda() for x in xs]
+            outs = [torch.full((len(x), 512), -2.0) for x in xs]
+            outs = [o.pin_memory() if host else o.cuda() for o in outs]
+            tickets = [m.submit_image(x, o) for x, o in zip(src, outs)]
+            for t in tickets:
+                m.wait(t, host=True)
+            for i in range(len(xs)):
+                assert np.array_equal(outs[i].cpu().numpy(), ref[i]), (depth, host, i)
+    with pytest.raises(RuntimeError):
+        m.wait(10 ** 9)
+    m.set_in_flight(1)
+    assert np.array_equal(m.precompute_embedding(xs[3]).numpy(), ref[3])
+    m.close()

@@ -6,22 +6,31 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_pipeline_equals_frame_by_frame_loop(sd_t):
+@pytest.mark.parametrize("mode", ["per_camera_copies", "one_copy_per_tick", "detector_slots"])
+def test_pipeline_equals_frame_by_frame_loop(sd_t, mode):
+    """per_camera_copies: a list of pinned frames, one upload each; one_copy_per_tick: the CameraBank's (N,H,W,3) tensor, a single
+    upload; detector_slots: in_flight=True, three batches in flight, each an upload -> detect -> download chain on its own slot."""
     from clearcam_amd.ocsort import OCSort
     from clearcam_amd.streams import StreamPipeline, make_cameras
     from clearcam_amd.yolov9 import YOLOv9
     H, W, N, T = 270, 480, 3, 7
     model = YOLOv9("t", 320, state_dict=sd_t, dtype="f32")
     cams = make_cameras(N, H, W, ring=3)
-    pipe = StreamPipeline(model, N, (H, W), depth=2, n_threads=2)
+    depth = 3 if mode == "detector_slots" else 2
+    pipe = StreamPipeline(model, N, (H, W), depth=depth, n_threads=2, in_flight=mode == "detector_slots")
+    assert pipe.in_flight == (mode == "detector_slots")
+    grab = (lambda: [c.read() for c in cams]) if mode == "per_camera_copies" else cams.read_all
     got = []
-    pipe.submit([c.read() for c in cams])
-    for _ in range(T - 1):
-        pipe.submit([c.read() for c in cams])
+    for _ in range(depth - 1):
+        pipe.submit(grab())
+    for _ in range(T - depth + 1):
+        pipe.submit(grab())
         preds, rows = pipe.collect()
         got.append((preds.copy(), rows))
-    preds, rows = pipe.collect()
-    got.append((preds.copy(), rows))
+    for _ in range(depth - 1):
+        preds, rows = pipe.collect()
+        got.append((preds.copy(), rows))
+    assert len(got) == T
     with pytest.raises(RuntimeError):
         pipe.collect()                                           # nothing in flight
     # the reference loop (clearcam.py:583-585), one camera and one frame at a time
