@@ -242,28 +242,26 @@ class _RowTable:
         self.truthy: List[bool] = [False]      # group has a crop whose track id is truthy (the `any(item[2] ...)` of :378)
         self.bad: List[bool] = [False]         # group has a *.jpg name event_img_info cannot parse (the reference raises on it)
         self.group: List[int] = []
-        self.oid: List[int] = []               # track id per row, -1 = None (no '_' in the name)
+        self.oid: List[Optional[int]] = []     # track id per row exactly as event_img_info returns it (any sign), None = no '_' in the name
 
     def describe(self, path: str) -> Tuple[int, int]:
         norm = path.replace("\\", "/")
         fn = os.path.basename(path)
         if not fn.lower().endswith(".jpg"):
-            return 0, -1
+            return 0, None
         d = norm[:norm.rfind("/") + 1]
         g = self.dir_id.get(d)
         if g is None:
             g = self.dir_id[d] = len(self.dirs)
             self.dirs.append(d); self.truthy.append(False); self.bad.append(False)
-        oid = -1
+        oid = None
         if "_" in fn:
             try:
                 oid = event_img_info(fn.split(".jpg")[0])["object_id"]
-                if oid < 0 or oid >= 1 << 62:
-                    raise ValueError
-            except Exception:                  # noqa: BLE001  unparsable / negative ids take the exact slow path at search time
+            except Exception:                  # noqa: BLE001  names the reference raises on take the exact slow path at search time
                 self.bad[g] = True
-                oid = -1
-        if oid > 0:
+                oid = None
+        if oid:                                # the reference's `any(item[2] ...)`: id 0 and None are falsy
             self.truthy[g] = True
         return g, oid
 
@@ -542,7 +540,7 @@ class ObjectFinder:
             best, loose = {}, []
             for r, sc in zip(rows, scores):
                 oid = table.oid[r]
-                if oid >= 0:
+                if oid is not None:
                     if oid not in best or sc > best[oid][1]:
                         best[oid] = (table.paths[r], sc)
                 else:
@@ -582,8 +580,15 @@ class ObjectFinder:
             rows, scs = idx[0][keep], sc[0][keep]
             order = np.argsort(rows, kind="stable")
             results = self._rank(table, rows[order].tolist(), [float(v) for v in scs[order]], grouped)
-            if rows.size < kk or (len(results) >= top_k and results[top_k - 1][1] > float(scs.min())):
+            if rows.size < kk:                              # every allowed row was a candidate: this IS the reference's loop
                 return results[:top_k]
+            if len(results) >= top_k and results[top_k - 1][1] > float(scs.min()):
+                # Bit-equal scores among the answers (duplicate crops): the reference orders them by the first appearance of their
+                # track id over ALL rows (dict order + stable sort), which a candidate list cannot know - rank the whole vector then.
+                head = [sc_ for _, sc_ in results[:top_k + 1]]
+                if len(set(head)) == len(head):
+                    return results[:top_k]
+                break
             if kk == 1024:
                 break
             kk = min(1024, kk * 4)

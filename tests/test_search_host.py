@@ -81,7 +81,7 @@ def reference_search(embeddings, text_embedding, top_k=10, cam_name=None, timest
     return results[:top_k]
 
 
-def make_world(rng, n, dim=32, cams=("front", "back", "yard"), days=("2026-01-01", "2026-01-02", "video"), n_ids=40, dup=0.05):
+def make_world(rng, n, dim=32, cams=("front", "back", "yard"), days=("2026-01-01", "2026-01-02", "video"), n_ids=40, dup=0.05, neg_ids=False):
     emb = {}
     base = "data/cameras"
     vecs = rng.standard_normal((n, dim)).astype(np.float32)
@@ -90,7 +90,7 @@ def make_world(rng, n, dim=32, cams=("front", "back", "yard"), days=("2026-01-01
         cam, day = cams[rng.integers(len(cams))], days[rng.integers(len(days))]
         kind = rng.random()
         if kind < 0.80:
-            name = f"{1700000000 + i}.5_{int(rng.integers(0, n_ids))}_{int(rng.integers(0, 80))}.jpg"     # track ids include 0 (falsy)
+            name = f"{1700000000 + i}.5_{int(rng.integers(-n_ids if neg_ids else 0, n_ids))}_{int(rng.integers(0, 80))}.jpg"     # track ids include 0 (falsy)
         elif kind < 0.88:
             name = f"snapshot{i}.jpg"                                                                   # no '_' -> no track id
         elif kind < 0.94:
@@ -127,6 +127,26 @@ def test_search_equals_reference_loop(seed):
         got = f.search(top_k=k, cam_name=cam, timestamp=ts, text_embedding=q)
         assert [p for p, _ in got] == [p for p, _ in want]
         assert np.allclose([s for _, s in got], [s for _, s in want], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_duplicate_crops_and_negative_ids_rank_like_the_reference(seed):
+    """(1) bit-equal scores (half the crops are duplicates of earlier ones): the reference orders tied answers by the
+    first appearance of their track id over ALL rows, so a candidate list that shows ties among the answers must hand over to the
+    full-vector path; (2) negative track ids are ids like any other (`object_id is not None`), not id-less crops."""
+    rng = np.random.default_rng(100 + seed)
+    dim = 16
+    emb = make_world(rng, 1200, dim, n_ids=25, dup=0.5, neg_ids=True)
+    emb = {p: v for p, v in emb.items() if not p.endswith(".JPG")}
+    f = finder_with(emb, dim)
+    for _ in range(20):
+        q = rng.standard_normal(dim).astype(np.float32)
+        cam = [None, "front", "back"][rng.integers(3)]
+        ts = [None, "2026-01-01", "2026-01-02"][rng.integers(3)]
+        k = int(rng.choice([1, 2, 5, 10, 30, 200]))
+        want = reference_search(emb, q, k, cam, ts)
+        got = f.search(top_k=k, cam_name=cam, timestamp=ts, text_embedding=q)
+        assert [p for p, _ in got] == [p for p, _ in want], (seed, k, cam, ts)
 
 
 def test_candidate_growth_and_full_fallback():
