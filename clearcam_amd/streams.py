@@ -244,9 +244,11 @@ def main() -> None:
     ap.add_argument("--resident", action="store_true", help="frames stay in HBM (no PCIe upload)")
     ap.add_argument("--thresh", type=float, default=0.25, help="tracker score threshold (clearcam's detection threshold setting)")
     ap.add_argument("--cls-bias-shift", type=float, default=0.0, help="move the synthetic class-logit biases (sparser detections)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight in the pipeline")
+    ap.add_argument("--in-flight", action="store_true", help="one detector slot per batch in flight (YOLOv9.submit: upload -> detect -> download chains that overlap)")
     a = ap.parse_args()
     model = YOLOv9(a.size, a.res, state_dict=shift_class_bias(synthetic_yolov9_state_dict(a.size, 1234), a.cls_bias_shift), dtype=a.dtype)
-    pipe = StreamPipeline(model, a.cams, (a.height, a.width), det_thresh=a.thresh)
+    pipe = StreamPipeline(model, a.cams, (a.height, a.width), depth=a.depth, det_thresh=a.thresh, in_flight=a.in_flight)
     cams = None if a.resident else make_cameras(a.cams, a.height, a.width)
     print(json.dumps(pipe.run(cams, a.batches)))
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU-box script: everything profiles/<tag>_* is made from.   bash tools/measure_round.sh r02d
-#   1 bench line (default bench.py run)            -> gpurun_out/<tag>_bench_line.json
+#   1 bench line (default bench.py run: three batches in flight + the back-to-back number) -> gpurun_out/<tag>_bench_line.json
 #   2 per-launch tables of the bench plan, B=64/1  -> gpurun_out/<tag>_yolo_per_launch.csv, <tag>_yolo_per_launch_b1.csv
-#   3 rocprofv3 --kernel-trace --stats, 10 replays -> gpurun_out/<tag>_yolo_kernel_stats.csv (+ .txt summary)
+#   3 rocprofv3 --kernel-trace --stats, 10 replays, ONE batch in flight (no launch shares the chip with another) -> gpurun_out/<tag>_yolo_kernel_stats.csv (+ .txt summary)
 #   4 rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel trace only) -> gpurun_out/pmc_traffic.json, <tag>_pmc_traffic.txt
 # The PMC record carries the digest of clearcam_amd/csrc; bench.py quotes it only while the digest matches, so run this on the final code
 # and run the bench LAST (step 1 is executed after step 4 for that reason).
