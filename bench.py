@@ -337,13 +337,14 @@ def stream_side_metrics(device_index: int, size: str, res: int, dtype: str) -> d
     from clearcam_amd.yolov9 import YOLOv9
     out = {}
     sd = synthetic_yolov9_state_dict(size, 1234)
-    cams = make_cameras(64)
+    banks = {64: make_cameras(64), 8: make_cameras(8)}          # one pinned bank per camera count: a tick goes up as ONE copy
     for key, n, shift in (("cams64", 64, -20.0), ("cams8", 8, -20.0), ("cams64_crowded", 64, 0.0)):
         m = YOLOv9(size, res, state_dict=shift_class_bias(sd, shift), dtype=dtype, device=device_index)
         pipe = StreamPipeline(m, n)
-        for c in cams:
-            c.t = 0
-        st = pipe.run(cams[:n], 24 if n > 8 else 60)
+        cams = banks[n]
+        if hasattr(cams, "t"):
+            cams.t = 0
+        st = pipe.run(cams, 24 if n > 8 else 60)
         out[key] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}
         pipe.close(); m.close()
     return out
