@@ -77,6 +77,9 @@ class CameraBank(list):
         return f
 
 
+_STREAMS: Dict[tuple, tuple] = {}            # (device, copy streams) -> ([copy streams], compute stream)
+
+
 class _Slot:
     def __init__(self, n, h, w, dev):
         import torch
@@ -101,8 +104,14 @@ class StreamPipeline:
         self.dev = torch.device("cuda", model.device)
         # high-priority streams take their hardware queue from a pool of their own: the uploads never queue behind a kernel of
         # some normal-priority stream that happens to share a queue (the runtime maps all streams of a class onto a few queues)
-        self.copy_streams = [torch.cuda.Stream(self.dev, priority=-1) for _ in range(max(1, copy_streams))]
-        self.copy_stream, self.compute_stream = self.copy_streams[0], torch.cuda.Stream(self.dev)
+        # One set of streams per device and process, shared by every pipeline on it: a second pipeline that drew fresh streams from
+        # torch's pool uploaded at 37 instead of 51 GB/s on this runtime (same code, same box; the hardware queue / DMA engine a new
+        # stream lands on is not ours to choose), so later pipelines keep the first one's.
+        key = (self.dev.index, max(1, copy_streams))
+        if key not in _STREAMS:
+            _STREAMS[key] = ([torch.cuda.Stream(self.dev, priority=-1) for _ in range(max(1, copy_streams))], torch.cuda.Stream(self.dev))
+        self.copy_streams, self.compute_stream = _STREAMS[key]
+        self.copy_stream = self.copy_streams[0]
         self.slots = [_Slot(n_cams, frame_hw[0], frame_hw[1], self.dev) for _ in range(depth)]
         # Defaults = the configuration that measured the same on every run: two batches in flight, one detector stream
         # (64 x 1080p: 6.9-7.1 k frames/s, 8 x 1080p: 3.9-4.1 k).  in_flight=True gives every batch in flight a detector slot of its
@@ -165,23 +174,31 @@ class StreamPipeline:
             s.done.record(st)
         self.submitted += 1
 
-    def collect(self):
-        """-> (preds (N,300,6) float32 ndarray view valid until the slot is reused, per-camera track rows or None)."""
-        if self.collected >= self.submitted:
-            raise RuntimeError("nothing in flight")
-        s = self.slots[self.collected % self.depth]
+    def _wait(self, s) -> np.ndarray:
+        """Block until slot s's rows are in its pinned host buffer; -> (N,300,6) float32 view, valid until the slot is reused."""
         if s.ticket is not None:
             self.model.wait(s.ticket, host=True)
         else:
             s.done.synchronize()
-        preds = s.host_out.numpy()
+        return s.host_out.numpy()
+
+    def _track(self, preds: np.ndarray, t_submit: float):
         rows = None
         self.n_dets += int((preds[..., 4] > np.float32(self.det_thresh)).sum())
         if self.track:
             t0 = time.perf_counter()
             rows = OCSort.update_many(self.trackers, preds, self.det_thresh, self.n_threads)
             self.track_s += time.perf_counter() - t0
-        self.latency.append(time.perf_counter() - s.t_submit)
+        self.latency.append(time.perf_counter() - t_submit)
+        return rows
+
+    def collect(self):
+        """-> (preds (N,300,6) float32 ndarray view valid until the slot is reused, per-camera track rows or None)."""
+        if self.collected >= self.submitted:
+            raise RuntimeError("nothing in flight")
+        s = self.slots[self.collected % self.depth]
+        preds = self._wait(s)
+        rows = self._track(preds, s.t_submit)
         self.collected += 1
         return preds, rows
 
@@ -196,13 +213,27 @@ class StreamPipeline:
             self.submit(grab()); self.collect()
         torch.cuda.synchronize(self.dev)
         self.track_s, self.latency, self.n_dets = 0.0, [], 0
+        # The trackers of batch k run on a worker thread (cc_ocsort_update_many releases the GIL) while this thread already queues the
+        # next upload + detect: with the tracker between a collect and the next submit, the upload of batch k+2 started ~3 ms into
+        # detect(k+1) and finished after it, leaving the GPU idle.  One worker, FIFO: every camera's tracker sees its frames in order.
+        from concurrent.futures import ThreadPoolExecutor
+        pool, pending = ThreadPoolExecutor(max_workers=1), None
         t0 = time.perf_counter()
-        for _ in range(n_batches):                               # `depth` batches in flight: the oldest is collected when the ring is full
-            if self.submitted - self.collected == self.depth:
-                self.collect()
-            self.submit(grab())
-        while self.collected < self.submitted:
-            self.collect()
+        for i in range(n_batches + self.depth):                  # `depth` batches in flight: the oldest is collected when the ring is full
+            if self.submitted - self.collected == self.depth or i >= n_batches:
+                if self.collected == self.submitted:
+                    break
+                s = self.slots[self.collected % self.depth]
+                preds = self._wait(s).copy()                     # the slot (and its host buffer) is handed straight back to submit()
+                if pending is not None:
+                    pending.result()
+                pending = pool.submit(self._track, preds, s.t_submit)
+                self.collected += 1
+            if i < n_batches:
+                self.submit(grab())
+        if pending is not None:
+            pending.result()
+        pool.shutdown()
         dt = time.perf_counter() - t0
         frames = n_batches * self.n
         nbytes = self.n * self.hw[0] * self.hw[1] * 3

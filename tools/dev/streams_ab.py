@@ -10,7 +10,7 @@ from clearcam_amd.yolov9 import YOLOv9  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 sd = shift_class_bias(synthetic_yolov9_state_dict("c", 1234), -20.0)
 cams = make_cameras(n, seed=100)
-for depth, infl, ncopy in ((2, False, 1), (3, True, 1), (2, False, 1), (2, False, 1)):
+for depth, infl, ncopy in ((2, False, 1), (2, False, 1), (3, False, 1), (2, False, 1)):
     m = YOLOv9("c", 640, state_dict=sd, dtype="f16")
     pipe = StreamPipeline(m, n, depth=depth, in_flight=infl, copy_streams=ncopy)
     mode = os.environ.get("AB_MODE", "")
