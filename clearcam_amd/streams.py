@@ -95,12 +95,12 @@ class StreamPipeline:
     """N cameras -> one GPU.  submit(frames) queues upload + detect + download; collect() waits for the oldest batch in
     flight and advances the N trackers.  Keep <= depth batches in flight (run() does)."""
 
-    def __init__(self, model, n_cams: int, frame_hw=(1080, 1920), depth: int = 2, det_thresh: float = 0.25,
+    def __init__(self, model, n_cams: int, frame_hw=(1080, 1920), depth: Optional[int] = None, det_thresh: float = 0.25,
                  tracker_kwargs: Optional[dict] = None, n_threads: Optional[int] = None, track: bool = True, copy_streams: int = 1,
-                 in_flight: bool = False):
+                 in_flight: Optional[bool] = None):
         import torch
         self.torch = torch
-        self.model, self.n, self.hw, self.depth = model, n_cams, tuple(frame_hw), depth
+        self.model, self.n, self.hw = model, n_cams, tuple(frame_hw)
         self.dev = torch.device("cuda", model.device)
         # high-priority streams take their hardware queue from a pool of their own: the uploads never queue behind a kernel of
         # some normal-priority stream that happens to share a queue (the runtime maps all streams of a class onto a few queues)
@@ -112,14 +112,19 @@ class StreamPipeline:
             _STREAMS[key] = ([torch.cuda.Stream(self.dev, priority=-1) for _ in range(max(1, copy_streams))], torch.cuda.Stream(self.dev))
         self.copy_streams, self.compute_stream = _STREAMS[key]
         self.copy_stream = self.copy_streams[0]
+        # Defaults by camera count (profiles/r03s_streams_ab*.txt, r03x_streams_small.txt).  Many cameras: the tick's upload is what
+        # has to hide, so two batches in flight on ONE detector stream with the copy stream beside it (64 x 1080p: 8.1-8.3 k frames/s,
+        # upload at 51 GB/s; with detector slots the 398 MB upload runs under two other batches' kernels at 30 GB/s: 5.2 k).  Up to
+        # 8 cameras the batch is too small to fill the GPU, so every batch in flight gets a detector slot of its own
+        # (YOLOv9.submit with pinned host tensors: upload -> detect -> download as one chain per slot, four chains overlapping):
+        # 8 x 1080p 5.0-5.6 k frames/s against 3.9-4.1 k (frames resident 6.6-6.9 k against 4.3 k).  At 16-32 cameras the slots were
+        # faster on some runs and slower on others (6.7 k / 4.3 k against 5.6 k at 16): not a default.
+        if in_flight is None:
+            in_flight = n_cams <= 8 and hasattr(model, "submit")
+        if depth is None:
+            depth = 4 if in_flight else 2
+        self.depth = depth
         self.slots = [_Slot(n_cams, frame_hw[0], frame_hw[1], self.dev) for _ in range(depth)]
-        # Defaults = the configuration that measured the same on every run: two batches in flight, one detector stream
-        # (64 x 1080p: 6.9-7.1 k frames/s, 8 x 1080p: 3.9-4.1 k).  in_flight=True gives every batch in flight a detector slot of its
-        # own (YOLOv9.submit with pinned host tensors: upload -> detect -> download as one chain per slot; with depth 3: 8 x 1080p
-        # 4.6 k frames/s, frames resident 6.2 k against 4.4 k; 64 x 1080p frames resident 9.6 k against 9.3 k, but with uploads 5.2 k:
-        # a 398 MB upload under two other batches' kernels drops to 30 GB/s).  depth=3 with one detector stream reached 8.3-8.5 k
-        # frames/s at 64 x 1080p (upload at 52 GB/s beside the detector) on some runs and 5.9 k on others, depending on which
-        # hardware queues the runtime gave the streams - not a default.  profiles/r03s_streams_ab*.txt.
         self.in_flight = bool(in_flight) and hasattr(model, "submit") and depth > 1
         if self.in_flight:
             model.set_in_flight(depth)
@@ -275,11 +280,12 @@ def main() -> None:
     ap.add_argument("--resident", action="store_true", help="frames stay in HBM (no PCIe upload)")
     ap.add_argument("--thresh", type=float, default=0.25, help="tracker score threshold (clearcam's detection threshold setting)")
     ap.add_argument("--cls-bias-shift", type=float, default=0.0, help="move the synthetic class-logit biases (sparser detections)")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight in the pipeline")
-    ap.add_argument("--in-flight", action="store_true", help="one detector slot per batch in flight (YOLOv9.submit: upload -> detect -> download chains that overlap)")
+    ap.add_argument("--depth", type=int, default=None, help="batches in flight in the pipeline (default: 4 with detector slots, else 2)")
+    ap.add_argument("--in-flight", type=int, default=None, choices=[0, 1],
+                    help="1: one detector slot per batch in flight (YOLOv9.submit: upload -> detect -> download chains that overlap); default: up to 8 cameras")
     a = ap.parse_args()
     model = YOLOv9(a.size, a.res, state_dict=shift_class_bias(synthetic_yolov9_state_dict(a.size, 1234), a.cls_bias_shift), dtype=a.dtype)
-    pipe = StreamPipeline(model, a.cams, (a.height, a.width), depth=a.depth, det_thresh=a.thresh, in_flight=a.in_flight)
+    pipe = StreamPipeline(model, a.cams, (a.height, a.width), depth=a.depth, det_thresh=a.thresh, in_flight=None if a.in_flight is None else bool(a.in_flight))
     cams = None if a.resident else make_cameras(a.cams, a.height, a.width)
     print(json.dumps(pipe.run(cams, a.batches)))
 
