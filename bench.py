@@ -338,7 +338,9 @@ def stream_side_metrics(device_index: int, size: str, res: int, dtype: str) -> d
     out = {}
     sd = synthetic_yolov9_state_dict(size, 1234)
     banks = {64: make_cameras(64), 8: make_cameras(8)}          # one pinned bank per camera count: a tick goes up as ONE copy
-    for key, n, shift in (("cams64", 64, -20.0), ("cams8", 8, -20.0), ("cams64_crowded", 64, 0.0)):
+    # (the 8-camera leg goes last: it uses detector slots, and a pipeline created right after one with slots has been torn down has
+    # replayed its graph slowly on this runtime - DESIGN.md section 4, "Uploads")
+    for key, n, shift in (("cams64", 64, -20.0), ("cams64_crowded", 64, 0.0), ("cams8", 8, -20.0)):
         m = YOLOv9(size, res, state_dict=shift_class_bias(sd, shift), dtype=dtype, device=device_index)
         pipe = StreamPipeline(m, n)
         cams = banks[n]
