@@ -197,7 +197,7 @@ def clip_side_metrics(device_index: int, dev) -> dict:
                 m.submit_image(x, embs[k % 3])
             torch.cuda.synchronize()
             return B / ((time.perf_counter() - t0) / reps)
-        out["image_embeds_per_sec_by_batch_3_in_flight"] = {str(b): round(rate3(b, 24 if b <= 16 else 9), 1) for b in (1, 2, 4, 8, 16, 32, 64)}
+        out["image_embeds_per_sec_by_batch_3_in_flight"] = {str(b): round(rate3(b, 24 if b <= 16 else 9), 1) for b in (1, 2, 4, 8, 16, 32, 64, 128, 255)}
         m.set_in_flight(1)
     except Exception as exc:                     # noqa: BLE001  a side metric
         out["image_embeds_per_sec_by_batch_3_in_flight"] = f"error: {type(exc).__name__}: {exc}"
