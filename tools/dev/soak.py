@@ -23,6 +23,27 @@ def one_round(n):
         x = preprocess_crops(crops, CLIP_TINY.image_size); e = clip.precompute_embedding(x.cpu().numpy()).numpy()
         if len(ix) + len(e) <= 200000: ix.add(e)
         ix.search(e[:8], 10); m(frame); face(f112); blaze(frame)
+# batches in flight: depth changes (stream + plan churn), device and pinned-host submissions, CLIP slots
+m2 = YOLOv9("t", 320, state_dict=synthetic_yolov9_state_dict("t", 1234), dtype="f16")
+fd = torch.from_numpy(rng.integers(0, 256, (4, 320, 320, 3), dtype=np.uint8)).cuda(); fh = fd.cpu().pin_memory()
+od = [torch.empty(4, 300, 6, device="cuda") for _ in range(4)]; oh = [torch.empty(4, 300, 6).pin_memory() for _ in range(4)]
+xc = torch.rand(2, 3, CLIP_TINY.image_size, CLIP_TINY.image_size, device="cuda") * 2 - 1
+ec = [torch.empty(2, CLIP_TINY.embed, device="cuda") for _ in range(3)]
+def flight_round(n):
+    for depth in (1, 3, 2, 4):
+        m2.set_in_flight(depth)
+        ts = [m2.submit(fh if k & 1 else fd, oh[k % depth] if k & 1 else od[k % depth]) for k in range(n)]
+        for t in ts[-depth:]:
+            m2.wait(t, host=True)
+    clip.set_in_flight(3)
+    ts = [clip.submit_image(xc, ec[k % 3]) for k in range(n)]
+    for t in ts[-3:]:
+        clip.wait(t, host=True)
+    clip.set_in_flight(1)
+    torch.cuda.synchronize()
+_orig_round = one_round
+def one_round(n):
+    _orig_round(n); flight_round(n)
 one_round(5); base = free(); t0 = time.time()
 for r in range(6):
     one_round(40); print(f"round {r}: free {free():.0f} MB (drift {base - free():+.1f} MB), index rows {len(ix)}", flush=True)
