@@ -4,7 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the detect hot path (letterbox -> 144 convs -> decode -> top-300 + mask NMS)
-over one batch of 64 synthetic 640x640 BGR uint8 frames that are already resident in HBM.  With N>1
+over one batch of 64 synthetic 640x640 BGR uint8 frames that are already resident in HBM.  The K timed steps are
+submitted round robin to `--in-flight` (default 3) slots of one handle (cc_yolo_submit: own stream, arena and graph
+per slot, so consecutive batches overlap on the GPU; bit-identical rows) and all complete inside the timed region;
+the same K steps as back-to-back cc_yolo_detect calls are reported beside it (`one_batch_in_flight`).  With N>1
 (launched by torch.distributed.run, one rank per GPU) every rank runs its own 64 cameras' frames —
 cameras shard one-per-GPU, there is no data-path collective for detection — and
 value = all ranks' frames / max-over-ranks time ("weak" scaling).
@@ -13,8 +16,9 @@ Environment (tests only): CLEARCAM_BENCH_BACKEND=gloo runs the N>1 plumbing on C
 the caller has put in place (tests/test_bench_multi.py mocks them); the default is "nccl" (RCCL) on cuda:LOCAL_RANK.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel family (conv_mfma_kernel): algorithmic FLOPs per step / its summed
-                duration per step, measured live with hipEvents on the launch stream (cc_yolo_profile)
+  roofline      dominant kernel family (the conv kernels): algorithmic FLOPs per step / their summed duration per
+                step with ONE batch in flight (rocprofv3's kernel durations when the committed trace matches the kernel
+                sources by digest, else live: whole-step hipGraph minus non-conv hipGraph, hipEvents on the launch stream)
   cpu_baseline  the PyTorch-CPU fp32 oracle (restatement of the reference; tinygrad's CPU path cannot
                 run offline) timed on this host's cores on a bounded sample, batch 1 as the reference runs it
 """
