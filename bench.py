@@ -545,7 +545,7 @@ def main() -> None:
         # Local work is exception-safe and the only collective (one all-reduce) is reached by every rank whatever happened.
         stats = torch.zeros(2, 4, dtype=torch.float64)          # per config: frames/s, fps per camera, H2D GB/s, ok flag
         err = ""
-        for ci, n_cams in enumerate((8, 64)):
+        for ci, n_cams in enumerate((64, 8)):
             try:
                 from clearcam_amd.streams import StreamPipeline, make_cameras
                 from clearcam_amd.weights import shift_class_bias
@@ -560,7 +560,7 @@ def main() -> None:
         tot = stats.clone().to(dev); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         neg = (-stats[:, 1]).clone().to(dev); dist.all_reduce(neg, op=dist.ReduceOp.MAX)      # min over ranks of fps per camera
         streams_multi = {}
-        for ci, n_cams in enumerate((8, 64)):
+        for ci, n_cams in enumerate((64, 8)):
             streams_multi[f"cams{n_cams}_per_gpu"] = {"cameras_total": n_cams * world, "ranks_ok": int(tot[ci, 3].item()),
                                                       "frames_per_sec_total": round(float(tot[ci, 0]), 1),
                                                       "min_fps_per_camera": round(-float(neg[ci]), 2),
