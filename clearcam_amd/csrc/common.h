@@ -12,6 +12,9 @@
 namespace cc {
 
 enum DType : int { F32 = 0, F16 = 1, BF16 = 2 };
+// C-ABI dtype 3 ("f16s"): f16 activations, every conv weight carried as TWO f16 planes W = W_hi + W_lo (ConvP::split). Storage type F16.
+constexpr int F16S = 3;
+inline int storage_dtype(int dt) { return dt == F16S ? (int)F16 : dt; }
 
 inline size_t dtype_size(int dt) { return dt == F32 ? 4 : 2; }
 
@@ -100,7 +103,7 @@ struct ConvP {
   int B, Hin, Win, Cin;          // logical input dims (after shift), Cin = s0.C + s1.C
   int Ho, Wo, Cout;
   int ks, stride, pad;
-  int Ktot;                      // ks*ks*Cin
+  int Ktot;                      // ks*ks*Cin (split weights: 2*ks*ks*Cin)
   int Kw;                        // weight row stride in elements (>= Ktot, zero padded to a multiple of 64)
   const void* w;                 // [Cout][Kw], storage dtype
   const float* bias;             // [Cout] or null
@@ -108,6 +111,12 @@ struct ConvP {
   const void* res; int res_cstride, res_coff; int res_f32;   // optional residual (same pixel grid as out)
   int act;                       // 0 none, 1 SiLU, 2 tanh-GELU, 3 PReLU (x > 0 ? x : slope[channel] * x), 4 ReLU applied AFTER the residual add
   const float* slope;            // [Cout] PReLU slopes (act 3), else null
+  // Split weights (C-ABI dtype "f16s"): W * 2^e = W_hi + W_lo, two f16 planes per filter tap - the weight row is
+  // [tap 0: hi(Cin) | lo(Cin)] [tap 1: hi | lo] ..., i.e. the K walk visits every tap's input channels twice (2 ks^2 "virtual taps")
+  // and both products land in the same f32 accumulator: ~22 significant weight bits at twice the MFMA count, activation traffic
+  // from HBM unchanged.  Ktot = 2 ks^2 Cin.  oscale = 2^-e undoes the per-layer power-of-two scale that keeps W_lo a NORMAL f16
+  // number (exact: the epilogue computes fma(acc, oscale, bias)).  split = 0: oscale is ignored (taken as 1).
+  int split; float oscale;
   int variant;                   // kernel choice: 0 auto; tests force 1 direct, 2 generic MFMA, 3 halo-resident 3x3, 4 weights-stationary 3x3, 5 single-barrier schedule with 256x256 tiles, 6 the same with 128x128 tiles, 7 eight-wave two-group 256x256 kernel, 8 wave-autonomous narrow 3x3, 9 few-tile configuration (narrow channel tiles, 3-4 LDS stages)
 };
 

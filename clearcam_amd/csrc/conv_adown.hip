@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_avg_s2_kernel(const ConvP p, cons
 }
 
 bool conv_adown_supported(int dt, const ConvP& p) {
-  return dt != F32 && p.s0.shift == -1 && p.s1.C == 0 && p.ks == 3 && p.stride == 2 && p.pad == 1 && p.Cin % 64 == 0 && p.Cin == p.s0.C &&
+  return dt != F32 && !p.split && p.s0.shift == -1 && p.s1.C == 0 && p.ks == 3 && p.stride == 2 && p.pad == 1 && p.Cin % 64 == 0 && p.Cin == p.s0.C &&
          p.Hin == p.s0.H - 1 && p.Win == p.s0.W - 1 && p.s0.coff % 8 == 0 && p.s0.cstride % 8 == 0 && p.Kw == 9 * p.Cin && !p.res;
 }
 

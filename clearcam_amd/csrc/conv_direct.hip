@@ -25,21 +25,23 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvP p) {
     for (int s = 0; s < p.ks; ++s) {
       const int iw = wo * p.stride - p.pad + s;
       if ((unsigned)iw >= (unsigned)p.Win) continue;
-      const T* wk = w + (r * p.ks + s) * p.Cin;
-      {
-        const Src& S = p.s0;
-        const T* x = reinterpret_cast<const T*>(S.ptr) + ((size_t)(b * S.H + (ih >> S.shift)) * S.W + (iw >> S.shift)) * S.cstride + S.coff;
-        for (int c = 0; c < S.C; ++c) acc = fmaf(to_f32<T>(x[c]), to_f32<T>(wk[c]), acc);
-      }
-      if (p.s1.C > 0) {
-        const Src& S = p.s1;
-        const T* x = reinterpret_cast<const T*>(S.ptr) + ((size_t)(b * S.H + (ih >> S.shift)) * S.W + (iw >> S.shift)) * S.cstride + S.coff;
-        const T* wk1 = wk + p.s0.C;
-        for (int c = 0; c < S.C; ++c) acc = fmaf(to_f32<T>(x[c]), to_f32<T>(wk1[c]), acc);
+      for (int h = 0; h <= p.split; ++h) {               // split weights: the tap's channels again against the low plane
+        const T* wk = w + ((r * p.ks + s) * (1 + p.split) + h) * p.Cin;
+        {
+          const Src& S = p.s0;
+          const T* x = reinterpret_cast<const T*>(S.ptr) + ((size_t)(b * S.H + (ih >> S.shift)) * S.W + (iw >> S.shift)) * S.cstride + S.coff;
+          for (int c = 0; c < S.C; ++c) acc = fmaf(to_f32<T>(x[c]), to_f32<T>(wk[c]), acc);
+        }
+        if (p.s1.C > 0) {
+          const Src& S = p.s1;
+          const T* x = reinterpret_cast<const T*>(S.ptr) + ((size_t)(b * S.H + (ih >> S.shift)) * S.W + (iw >> S.shift)) * S.cstride + S.coff;
+          const T* wk1 = wk + p.s0.C;
+          for (int c = 0; c < S.C; ++c) acc = fmaf(to_f32<T>(x[c]), to_f32<T>(wk1[c]), acc);
+        }
       }
     }
   }
-  float t = acc + (p.bias ? p.bias[n] : 0.f);
+  float t = fmaf(acc, p.split ? p.oscale : 1.0f, p.bias ? p.bias[n] : 0.f);
   if (p.act == 1) t = t / (1.0f + expf(-t));
   else if (p.act == 2) t = 0.5f * t * (1.0f + tanhf(0.7978845608028654f * (t + 0.044715f * t * t * t)));
   else if (p.act == 3) t = t > 0.f ? t : p.slope[n] * t;

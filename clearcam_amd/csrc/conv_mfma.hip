@@ -114,9 +114,9 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
     wcur[i] = ok ? reinterpret_cast<const char*>(p.w) + ((size_t)n * p.Kw + chunk * E) * sizeof(T) : reinterpret_cast<const char*>(&g_zero16);
     winc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
   }
-  int k0 = chunk * E, kc, kr, ks_;                     // this thread's k index; its channel, tap row, tap col
-  if (k0 < p.Cin) { kc = k0; kr = 0; ks_ = 0; }
-  else { const int tap = k0 / p.Cin; kc = k0 - tap * p.Cin; kr = tap / p.ks; ks_ = tap - kr * p.ks; }
+  int k0 = chunk * E, kc, kr, ks_, vt;                 // this thread's k index; its channel, tap row, tap col; virtual tap (split weights: two per tap)
+  if (k0 < p.Cin) { kc = k0; kr = 0; ks_ = 0; vt = 0; }
+  else { vt = k0 / p.Cin; kc = k0 - vt * p.Cin; const int tap = vt >> p.split; kr = tap / p.ks; ks_ = tap - kr * p.ks; }
 
   auto retarget = [&]() {                              // SIMPLE: (kr, ks_, kc) changed tap -> new pointers
     const bool kok = kr < p.ks;                        // k0 < Ktot
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
 #pragma unroll
     for (int i = 0; i < WR; ++i) wcur[i] += winc[i];
     if (kc >= p.Cin) {
-      do { kc -= p.Cin; if (++ks_ == p.ks) { ks_ = 0; ++kr; } } while (kc >= p.Cin);
+      do { kc -= p.Cin; ++vt; if (next_filter_tap(vt, p.split)) { if (++ks_ == p.ks) { ks_ = 0; ++kr; } } } while (kc >= p.Cin);
       if constexpr (SIMPLE) retarget();
     } else if constexpr (SIMPLE) {
 #pragma unroll
@@ -284,9 +284,9 @@ __global__ __launch_bounds__(256, (TS == 256 ? 1 : 2)) void conv_big_kernel(cons
     wcur[i] = ok ? reinterpret_cast<const char*>(p.w) + ((size_t)n * p.Kw + chunk * E) * sizeof(T) : reinterpret_cast<const char*>(&g_zero16);
     winc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
   }
-  int k0 = chunk * E, kc, kr, ks_;
-  if (k0 < p.Cin) { kc = k0; kr = 0; ks_ = 0; }
-  else { const int tap = k0 / p.Cin; kc = k0 - tap * p.Cin; kr = tap / p.ks; ks_ = tap - kr * p.ks; }
+  int k0 = chunk * E, kc, kr, ks_, vt;
+  if (k0 < p.Cin) { kc = k0; kr = 0; ks_ = 0; vt = 0; }
+  else { vt = k0 / p.Cin; kc = k0 - vt * p.Cin; const int tap = vt >> p.split; kr = tap / p.ks; ks_ = tap - kr * p.ks; }
   auto retarget = [&]() {
     const bool kok = kr < p.ks;
     const int tbit = kr * p.ks + ks_;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, (TS == 256 ? 1 : 2)) void conv_big_kernel(cons
 #pragma unroll
     for (int i = 0; i < WR; ++i) wcur[i] += winc[i];
     if (kc >= p.Cin) {
-      do { kc -= p.Cin; if (++ks_ == p.ks) { ks_ = 0; ++kr; } } while (kc >= p.Cin);
+      do { kc -= p.Cin; ++vt; if (next_filter_tap(vt, p.split)) { if (++ks_ == p.ks) { ks_ = 0; ++kr; } } } while (kc >= p.Cin);
       retarget();
     } else {
 #pragma unroll
@@ -623,7 +623,8 @@ template <class T> static bool supported_t(const ConvP& p) {
   if (!src_ok(p.s0) || !src_ok(p.s1)) return false;
   if (p.Cin % E || p.Cout % 4 || p.out_coff % 4 || p.out_cstride % 4) return false;
   if (p.res && (p.res_coff % 4 || p.res_cstride % 4)) return false;
-  if (p.s0.C + p.s1.C != p.Cin || p.Ktot != p.ks * p.ks * p.Cin) return false;
+  if (p.s0.C + p.s1.C != p.Cin || p.Ktot != p.ks * p.ks * p.Cin * (p.split ? 2 : 1)) return false;
+  if (p.split && (sizeof(T) != 2 || p.s0.shift < 0)) return false;     // split weights: 16-bit storage, no averaging loader
   if (p.Kw < (p.Ktot + 8 * E - 1) / (8 * E) * (8 * E)) return false;      // weight rows must cover whole K steps
   if ((long)p.B * p.Ho * p.Wo >= (1L << 31) || (long)p.Ho * p.Wo >= (1L << 22)) return false;
   return true;
@@ -732,7 +733,7 @@ template <class T, int BN> static void launch_halo(const ConvP& p, hipStream_t s
 // slower for Cout = 320 (64-wide channel tiles reload the patch five times), for ragged coverage (40x40) and for the
 // 64-channel layers (those are latency-chain bound, see conv3x3_ws_kernel).  Tests force it with variant 3.
 static bool halo_legal(const ConvP& p) {
-  return p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && p.Cin % 64 == 0 && p.Hin == p.Ho && p.Win == p.Wo;
+  return !p.split && p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && p.Cin % 64 == 0 && p.Hin == p.Ho && p.Win == p.Wo;
 }
 static bool halo_applicable(const ConvP& p) {
   static int on = -1;
@@ -765,7 +766,7 @@ template <class T, int CIN, int COUT> static void launch_ws(const ConvP& p, hipS
 
 // narrow 3x3 s1 p1 layers: Cin in {32, 64}, Cout <= 64 (a multiple of 8), one source
 static bool ws_legal(const ConvP& p) {
-  return p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && (p.Cin == 32 || p.Cin == 64) &&
+  return !p.split && p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && (p.Cin == 32 || p.Cin == 64) &&
          p.Cout <= 64 && p.Cout % 8 == 0 && p.Hin == p.Ho && p.Win == p.Wo;
 }
 static bool ws_applicable(const ConvP& p) {

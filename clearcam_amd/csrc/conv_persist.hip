@@ -35,8 +35,8 @@ template <> struct Mma32<f16_t> {
   }
 };
 
-template <class T, int ACT> __device__ __forceinline__ float act_bias(float x, float b, float slope) {
-  float v = activate<T, ACT>(x + b);
+template <class T, int ACT> __device__ __forceinline__ float act_bias(float osc, float x, float b, float slope) {
+  float v = activate<T, ACT>(__builtin_fmaf(x, osc, b));       // osc = 1 unless the weights are split (conv_tile.h out_scale)
   if constexpr (ACT == 3) v = v > 0.f ? v : slope * v;
   return v;
 }
@@ -65,17 +65,19 @@ __global__ __launch_bounds__(512) void conv_persist_kernel(const ConvP p, const 
   const char* cur[XR]; unsigned inc[XR];
   const char* wptr = nullptr;
   const size_t wpass = (size_t)RPP * p.Kw * sizeof(T);
-  int kc = 0, tap = 0, pt = 0, wt = 0, m0 = 0, n0 = 0;
+  int kc = 0, vt = 0, pt = 0, wt = 0, m0 = 0, n0 = 0;
   const int nkt = (p.Ktot + BK - 1) / BK;
+  const float osc = out_scale(p);
 
   auto retarget = [&]() {
+    const int tap = vt >> p.split;                       // split weights: virtual taps 2t, 2t+1 read filter tap t's channels (hi / lo plane)
     const int kr = a.two ? 0 : tap / p.ks, ks_ = a.two ? 0 : tap - kr * p.ks;
     const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc + chunk * E) * (long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const RowInfo ri = rinfo[i];
       const bool ok = a.two ? ri.ptr != nullptr : (bool)((ri.aux >> tap) & 1u);
-      const char* src = (a.two && tap) ? reinterpret_cast<const char*>(ri.aux) : ri.ptr;
+      const char* src = (a.two && (vt & 1)) ? reinterpret_cast<const char*>(ri.aux) : ri.ptr;
       cur[i] = ok ? src + delta : reinterpret_cast<const char*>(&g_zero16);
       inc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
     }
@@ -120,12 +122,12 @@ __global__ __launch_bounds__(512) void conv_persist_kernel(const ConvP p, const 
       rinfo[i] = ri;
     }
     wptr = reinterpret_cast<const char*>(p.w) + ((size_t)(n0 + prow) * p.Kw + chunk * E) * sizeof(T);
-    kc = 0; tap = 0; pt = 0; wt = 0;
+    kc = 0; vt = 0; pt = 0; wt = 0;
     retarget();
   };
   auto advance_p = [&]() {
     kc += BK;
-    if (kc == (a.two ? (tap ? p.s1.C : p.s0.C) : p.Cin)) { kc = 0; ++tap; retarget(); }
+    if (kc == (a.two ? ((vt & 1) ? p.s1.C : p.s0.C) : p.Cin)) { kc = 0; ++vt; retarget(); }
     else {
 #pragma unroll
       for (int i = 0; i < XR; ++i) cur[i] += inc[i];
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(512) void conv_persist_kernel(const ConvP p, const 
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const f32x4 av = acc[j][2 * r + ib];
-            float v0 = act_bias<T, ACT>(av[0], b4[j].x, s4[j].x), v1 = act_bias<T, ACT>(av[1], b4[j].y, s4[j].y);
-            float v2 = act_bias<T, ACT>(av[2], b4[j].z, s4[j].z), v3 = act_bias<T, ACT>(av[3], b4[j].w, s4[j].w);
+            float v0 = act_bias<T, ACT>(osc, av[0], b4[j].x, s4[j].x), v1 = act_bias<T, ACT>(osc, av[1], b4[j].y, s4[j].y);
+            float v2 = act_bias<T, ACT>(osc, av[2], b4[j].z, s4[j].z), v3 = act_bias<T, ACT>(osc, av[3], b4[j].w, s4[j].w);
             if constexpr (ACT == 4) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             const int row = ib * 16 + fr, cl = j * 2 + (fg >> 1);
             *reinterpret_cast<uint2*>(stg + row * 128 + ((cl ^ (row & 7)) * 16) + (fg & 1) * 8) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(512) void conv_persist_kernel(const ConvP p, const 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x16 av = acc32[ws][r];
-            float v0 = act_bias<T, ACT>(av[4 * q + 0], b4[ws][q].x, s4[ws][q].x), v1 = act_bias<T, ACT>(av[4 * q + 1], b4[ws][q].y, s4[ws][q].y);
-            float v2 = act_bias<T, ACT>(av[4 * q + 2], b4[ws][q].z, s4[ws][q].z), v3 = act_bias<T, ACT>(av[4 * q + 3], b4[ws][q].w, s4[ws][q].w);
+            float v0 = act_bias<T, ACT>(osc, av[4 * q + 0], b4[ws][q].x, s4[ws][q].x), v1 = act_bias<T, ACT>(osc, av[4 * q + 1], b4[ws][q].y, s4[ws][q].y);
+            float v2 = act_bias<T, ACT>(osc, av[4 * q + 2], b4[ws][q].z, s4[ws][q].z), v3 = act_bias<T, ACT>(osc, av[4 * q + 3], b4[ws][q].w, s4[ws][q].w);
             if constexpr (ACT == 4) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             const int cl = ws * 4 + q;
             *reinterpret_cast<uint2*>(stg + fr * 128 + ((cl ^ (fr & 7)) * 16) + fh * 8) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
@@ -391,8 +393,8 @@ __global__ __launch_bounds__(512) void conv_persist_kernel(const ConvP p, const 
           const f32x4 av = acc[j][k];
           const int cl = j * 4 + fg;
           *reinterpret_cast<float4*>(stg + fr * 256 + ((cl ^ (fr & 15)) * 16)) =
-              make_float4(act_bias<T, ACT>(av[0], b4[j].x, s4[j].x), act_bias<T, ACT>(av[1], b4[j].y, s4[j].y),
-                          act_bias<T, ACT>(av[2], b4[j].z, s4[j].z), act_bias<T, ACT>(av[3], b4[j].w, s4[j].w));
+              make_float4(act_bias<T, ACT>(osc, av[0], b4[j].x, s4[j].x), act_bias<T, ACT>(osc, av[1], b4[j].y, s4[j].y),
+                          act_bias<T, ACT>(osc, av[2], b4[j].z, s4[j].z), act_bias<T, ACT>(osc, av[3], b4[j].w, s4[j].w));
         }
       } else {
         const int fr = lane & 31, fh = lane >> 5, r = k >> 1, half = k & 1;
@@ -406,8 +408,8 @@ __global__ __launch_bounds__(512) void conv_persist_kernel(const ConvP p, const 
               const float4 b = b4[ws * 4 + q], sl = s4[ws * 4 + q];
               const int cl = ws * 8 + q * 2 + fh;
               *reinterpret_cast<float4*>(stg + row * 256 + ((cl ^ (row & 15)) * 16)) =
-                  make_float4(act_bias<T, ACT>(av[4 * q + 0], b.x, sl.x), act_bias<T, ACT>(av[4 * q + 1], b.y, sl.y),
-                              act_bias<T, ACT>(av[4 * q + 2], b.z, sl.z), act_bias<T, ACT>(av[4 * q + 3], b.w, sl.w));
+                  make_float4(act_bias<T, ACT>(osc, av[4 * q + 0], b.x, sl.x), act_bias<T, ACT>(osc, av[4 * q + 1], b.y, sl.y),
+                              act_bias<T, ACT>(osc, av[4 * q + 2], b.z, sl.z), act_bias<T, ACT>(osc, av[4 * q + 3], b.w, sl.w));
             }
         }
       }

@@ -106,15 +106,16 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   const size_t wpass = (size_t)RPP * p.Kw * sizeof(T);
   // K walk: Cin is a multiple of 64 (checked on the host), so a K tile never straddles two filter taps and every thread
   // changes tap at the same tile
-  int kc = 0, tap = 0;                                 // channel offset of the current tile inside its tap; tap index r * ks + s
+  int kc = 0, vt = 0;                                  // channel offset of the current tile inside its tap; virtual tap (tap index r * ks + s, doubled for split weights; the source index of a Concat)
   auto retarget = [&]() {
+    const int tap = vt >> p.split;                       // split weights: virtual taps 2t, 2t+1 read filter tap t's channels (hi / lo plane)
     const int kr = a.two ? 0 : tap / p.ks, ks_ = a.two ? 0 : tap - kr * p.ks;
     const long delta = ((long)(kr * p.s0.W + ks_) * p.s0.cstride + kc + chunk * E) * (long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
       const RowInfo ri = rinfo[i];
       const bool ok = a.two ? ri.ptr != nullptr : (bool)((ri.aux >> tap) & 1u);
-      const char* src = (a.two && tap) ? reinterpret_cast<const char*>(ri.aux) : ri.ptr;   // two sources: `tap` counts the source
+      const char* src = (a.two && (vt & 1)) ? reinterpret_cast<const char*>(ri.aux) : ri.ptr;   // two sources: the low bit of `vt` counts the source
       if constexpr (BUF) cur32[i] = ok ? (unsigned)((src + delta) - reinterpret_cast<const char*>(p.s0.ptr)) : 0xffffffffu;
       else cur[i] = ok ? src + delta : reinterpret_cast<const char*>(&g_zero16);
       inc[i] = ok ? (unsigned)(BK * sizeof(T)) : 0u;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(512) void conv_phase_kernel(const ConvP p, const Co
   retarget();
   auto advance_p = [&]() {
     kc += BK;
-    if (kc == (a.two ? (tap ? p.s1.C : p.s0.C) : p.Cin)) { kc = 0; ++tap; retarget(); }
+    if (kc == (a.two ? ((vt & 1) ? p.s1.C : p.s0.C) : p.Cin)) { kc = 0; ++vt; retarget(); }
     else {
 #pragma unroll
       for (int i = 0; i < XR; ++i) { if constexpr (BUF) cur32[i] += inc[i]; else cur[i] += inc[i]; }

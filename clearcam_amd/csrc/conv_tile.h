@@ -20,6 +20,13 @@ struct ConvAux {
   int two;                // conv_phase_kernel: 1x1 conv over the channel concat of two sources (either may be read nearest-upsampled)
 };
 
+// accumulator -> pre-activation value: fma(acc, out_scale, bias).  1 unless the layer's weights are split (ConvP::split), where it is
+// the exact power of two that undoes the weight scale; fma(acc, 1, b) IS acc + b, so the other modes keep their bits.
+__device__ __forceinline__ float out_scale(const ConvP& p) { return p.split ? p.oscale : 1.0f; }
+// K walk over "virtual taps" (ConvP::split): leaving virtual tap vt - 1 for vt moves to the next filter tap unless vt is the
+// low-plane pass of the same tap.
+__device__ __forceinline__ bool next_filter_tap(int vt, int split) { return !(vt & split); }
+
 template <class T, int ACT> __device__ __forceinline__ float activate(float x) {
   if constexpr (ACT == 1) {            // SiLU
     if constexpr (sizeof(T) == 4) return x / (1.0f + expf(-x));
@@ -94,6 +101,7 @@ template <class T, int ACT, int BN, int MI, int NJ>
 __device__ __forceinline__ void stage_tile(const ConvP& p, const f32x4 (&acc)[NJ][MI], char* tilep, int n0, int wm0, int wn0, int fr, int fg) {
   constexpr int ROWB = BN * 2, CPR = BN / 8;
   auto rowswz = [](int row) { if constexpr (CPR <= 16) return row / (16 / CPR); else return row * (CPR / 16); };
+  const float osc = out_scale(p);
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int nl = wn0 + j * 16 + fg * 4, n = n0 + nl;
@@ -103,8 +111,8 @@ __device__ __forceinline__ void stage_tile(const ConvP& p, const f32x4 (&acc)[NJ
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const f32x4 av = acc[j][i];
-      float v0 = activate<T, ACT>(av[0] + b4.x), v1 = activate<T, ACT>(av[1] + b4.y);
-      float v2 = activate<T, ACT>(av[2] + b4.z), v3 = activate<T, ACT>(av[3] + b4.w);
+      float v0 = activate<T, ACT>(__builtin_fmaf(av[0], osc, b4.x)), v1 = activate<T, ACT>(__builtin_fmaf(av[1], osc, b4.y));
+      float v2 = activate<T, ACT>(__builtin_fmaf(av[2], osc, b4.z)), v3 = activate<T, ACT>(__builtin_fmaf(av[3], osc, b4.w));
       if constexpr (ACT == 3) { v0 = v0 > 0.f ? v0 : s4.x * v0; v1 = v1 > 0.f ? v1 : s4.y * v1; v2 = v2 > 0.f ? v2 : s4.z * v2; v3 = v3 > 0.f ? v3 : s4.w * v3; }
       if constexpr (ACT == 4) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }   // staged path has no residual
       const int row = wm0 + i * 16 + fr;
@@ -118,6 +126,7 @@ __device__ __forceinline__ void stage_tile(const ConvP& p, const f32x4 (&acc)[NJ
 // from being promoted to registers) + optional residual, 4 consecutive channels of one pixel stored from registers
 template <class T, int ACT, int MI, int NJ>
 __device__ __forceinline__ void direct_tile(const ConvP& p, const f32x4 (&acc)[NJ][MI], const long (&mrow)[MI], int nbase) {
+  const float osc = out_scale(p);
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int n = nbase + j * 16;
@@ -133,7 +142,7 @@ __device__ __forceinline__ void direct_tile(const ConvP& p, const f32x4 (&acc)[N
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = activate<T, ACT>(av[e] + bv[e]);
+          v[e] = activate<T, ACT>(__builtin_fmaf(av[e], osc, bv[e]));
           if constexpr (ACT == 3) v[e] = v[e] > 0.f ? v[e] : sv[e] * v[e];
         }
         if (p.res) {

@@ -161,7 +161,7 @@ template <class T, int CIN, int COUT, int NW> static void launch_wave(const Conv
 }
 
 bool conv_wave_legal(const ConvP& p) {
-  return p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && (p.Cin == 32 || p.Cin == 64) &&
+  return !p.split && p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && (p.Cin == 32 || p.Cin == 64) &&
          (p.Cout == 32 || p.Cout == 64) && p.Hin == p.Ho && p.Win == p.Wo && (long)p.B * ((p.Ho + 1) / 2) * ((p.Wo + 15) / 16) < (1L << 22);
 }
 

@@ -38,7 +38,7 @@ static const Arch kArch[] = {
 };
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
-struct PackedConv { void* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 0, kw = 0; double macs_px = 0; };
+struct PackedConv { void* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 0, kw = 0; double macs_px = 0; int split = 0; float oscale = 1.0f; };
 
 struct Buf { int H, W, C; bool f32; size_t off; };
 struct View { int buf; int coff; int C; };
@@ -86,7 +86,8 @@ using namespace cc;
 
 struct cc_yolo {
   const Arch* arch = nullptr;
-  int res = 640, dtype = BF16, device = 0;
+  int res = 640, dtype = BF16, device = 0;              // dtype: STORAGE type of activations and weights
+  int wsplit = 0;                                      // C-ABI dtype 3 ("f16s"): f16 storage, every conv weight as two f16 planes (ConvP::split)
   hipStream_t stream = nullptr;
   std::vector<hipStream_t> side;                       // streams of lanes 1.. while a plan is captured (run_ops_lanes)
   // Batches in flight (cc_yolo_submit / cc_yolo_wait): slot i > 0 has its own stream and its own plans (arena, graph), so the tail of
@@ -115,9 +116,14 @@ void convert_f32_to(int dt, const float* src, void* dst, size_t n) {
 
 // Pack a list of OIHW convs over the same input into one [sum Cout][k*k*cin_pad] matrix (+ bias).
 // groups>1 convs become block-diagonal.  cin_pad >= cin zero-pads the channel axis (stem).
+// split (f16 storage only): every tap's cin_pad channels appear twice, [hi | lo] with  w * 2^e = hi + lo  (hi = f16(w 2^e), lo =
+// f16(w 2^e - hi)); 2^e is the power of two that puts the matrix's largest magnitude in [2^14, 2^15), so that lo (~2^-11 of hi)
+// stays a NORMAL f16 number for every weight down to ~4e-6 of the largest - the planes hold ~22 significant bits of w, and
+// PackedConv::oscale = 2^-e (exact) is applied to the f32 accumulator in the conv epilogue.
 static PackedConv pack_convs(int dt, const std::vector<const HostTensor*>& ws, const std::vector<const HostTensor*>& bs,
-                             const std::vector<int>& groups, int cin_pad) {
+                             const std::vector<int>& groups, int cin_pad, int split = 0) {
   PackedConv pc;
+  CC_CHECK(!split || dt == F16, "split weights need f16 storage");
   const int k = (int)ws[0]->shape[2];
   int cin = 0, cout = 0;
   for (size_t t = 0; t < ws.size(); ++t) {
@@ -127,9 +133,17 @@ static PackedConv pack_convs(int dt, const std::vector<const HostTensor*>& ws, c
     cin = ci; cout += (int)ws[t]->shape[0];
   }
   const int cp = cin_pad > cin ? cin_pad : cin;
-  const size_t kreal = (size_t)k * k * cp;
+  const int planes = split ? 2 : 1;
+  const size_t kreal = (size_t)k * k * cp * planes;
   const size_t ktot = (kreal + 63) / 64 * 64;          // row stride: zero padded to a whole number of K steps
   std::vector<float> w((size_t)cout * ktot, 0.f), bias(cout, 0.f);
+  float scale = 1.0f;
+  if (split) {
+    float mx = 0.f;
+    for (size_t t = 0; t < ws.size(); ++t) for (float v : ws[t]->data) mx = std::max(mx, std::fabs(v));
+    if (mx > 0.f && std::isfinite(mx)) scale = std::ldexp(1.0f, 14 - std::ilogb(mx));      // mx * scale in [2^14, 2^15)
+    pc.split = 1; pc.oscale = 1.0f / scale;
+  }
   int n0 = 0;
   for (size_t t = 0; t < ws.size(); ++t) {
     const int co = (int)ws[t]->shape[0], cig = (int)ws[t]->shape[1], g = groups[t], cog = co / g;
@@ -138,8 +152,17 @@ static PackedConv pack_convs(int dt, const std::vector<const HostTensor*>& ws, c
       const int grp = n / cog;
       for (int c = 0; c < cig; ++c)
         for (int r = 0; r < k; ++r)
-          for (int s = 0; s < k; ++s)
-            w[(size_t)(n0 + n) * ktot + (size_t)(r * k + s) * cp + grp * cig + c] = ws[t]->data[(((size_t)n * cig + c) * k + r) * k + s];
+          for (int s = 0; s < k; ++s) {
+            const float v = ws[t]->data[(((size_t)n * cig + c) * k + r) * k + s];
+            float* row = &w[(size_t)(n0 + n) * ktot];
+            if (!split) row[(size_t)(r * k + s) * cp + grp * cig + c] = v;
+            else {
+              const float vs = v * scale;                        // exact: a power of two
+              const float hi = (float)(f16_t)vs;
+              row[(size_t)((r * k + s) * 2 + 0) * cp + grp * cig + c] = hi;
+              row[(size_t)((r * k + s) * 2 + 1) * cp + grp * cig + c] = vs - hi;   // exact in f32; rounded to f16 below
+            }
+          }
       if (bs[t]) bias[n0 + n] = bs[t]->data[n];
     }
     n0 += co;
@@ -207,7 +230,7 @@ struct Builder {
       CC_CHECK(b != Y->host.end(), "missing parameter " + n + ".bias");
       ws.push_back(&w->second); bs.push_back(&b->second);
     }
-    return Y->packed[key] = pack_convs(Y->dtype, ws, bs, groups, cin_pad);
+    return Y->packed[key] = pack_convs(Y->dtype, ws, bs, groups, cin_pad, Y->wsplit);
   }
 
   Src src(const In& in) {
@@ -235,7 +258,8 @@ struct Builder {
     c.Ho = (c.Hin + 2 * c.pad - c.ks) / stride + 1; c.Wo = (c.Win + 2 * c.pad - c.ks) / stride + 1;
     const Buf& ob = P->bufs[out.buf];
     CC_CHECK(ob.H == c.Ho && ob.W == c.Wo && out.C == pc.cout, "conv output view mismatch");
-    c.Cout = pc.cout; c.Ktot = c.ks * c.ks * c.Cin; c.Kw = pc.kw;
+    c.Cout = pc.cout; c.Ktot = c.ks * c.ks * c.Cin * (pc.split ? 2 : 1); c.Kw = pc.kw;
+    c.split = pc.split; c.oscale = pc.oscale;
     c.w = pc.w; c.bias = pc.bias;
     c.out = (void*)(intptr_t)out.buf; c.out_cstride = ob.C; c.out_coff = out.coff; c.out_f32 = ob.f32;
     if (res) { const Buf& rb = P->bufs[res->buf]; c.res = (const void*)(intptr_t)res->buf; c.res_cstride = rb.C; c.res_coff = res->coff; c.res_f32 = rb.f32; }
@@ -251,7 +275,7 @@ struct Builder {
   // The detector's first conv straight from the frames (stem_fused_kernel); 16-bit storage only, CLEARCAM_FUSE_STEM=0 disables.
   bool fuse_stem(int cout) const {
     static const bool on = [] { const char* e = getenv("CLEARCAM_FUSE_STEM"); return e ? atoi(e) != 0 : true; }();
-    return on && Y->cin_pad() == 8 && stem_fused_supported(Y->dtype, cout);
+    return on && !Y->wsplit && Y->cin_pad() == 8 && stem_fused_supported(Y->dtype, cout);
   }
   // the fused kernel's weight layout ([Cout][32], k = r*9 + s*3 + c), derived once per handle from the packed conv weights
   const void* stem_weights(const std::string& name, const PackedConv& pc) {
@@ -307,7 +331,7 @@ struct Builder {
   bool fuse_csp(View in, int hid, int index) const {
     const char* e = getenv("CLEARCAM_FUSE_CSP");
     const int level = e ? atoi(e) : 2;
-    if (level == 0 || (level == 1 && hid != 32)) return false;
+    if (level == 0 || (level == 1 && hid != 32) || Y->wsplit) return false;    // the fused kernel holds one weight plane
     const char* only = dev_env("CLEARCAM_CSP_ONLY");                // development: fuse just this block (csp_debug.py)
     if (only && atoi(only) != index) return false;
     return a.rep_n == 1 && csp_fused_supported(Y->dtype, hid) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0;
@@ -385,7 +409,7 @@ struct Builder {
   // CLEARCAM_FUSE_ADOWN=1 turns it on wherever the shape allows.  Read per plan.
   bool fuse_adown(View in) const {
     const char* e = getenv("CLEARCAM_FUSE_ADOWN");
-    if (!e || atoi(e) == 0) return false;
+    if (!e || atoi(e) == 0 || Y->wsplit) return false;
     return Y->dtype != F32 && in.C % 64 == 0 && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0;
   }
   View down(const std::string& p, View in, int cout) {   // ADown :40-52 / AConv :54-63
@@ -467,7 +491,7 @@ struct Builder {
   // level + decode_kernel (and with them the "raw<l>" parity taps, which the f32 mode always has).
   bool fuse_head_tail() const {
     const char* e = getenv("CLEARCAM_FUSE_HEAD");
-    return (!e || atoi(e) != 0) && head_tail_supported(Y->dtype, a.cls_hidden);
+    return (!e || atoi(e) != 0) && !Y->wsplit && head_tail_supported(Y->dtype, a.cls_hidden);
   }
   // One level of DDetect (:157-220): the level's conv chain runs on its own lane - it only needs that level's feature map, so
   // P3's 1.3 ms of 3x3 convs overlap the neck's way down to P4 / P5 (whose 40x40 / 20x20 launches leave CUs idle) instead of queueing
@@ -930,7 +954,7 @@ int cc_device_count(int* n) { CC_API_BEGIN CC_HIP(hipGetDeviceCount(n)); CC_API_
 int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device) {
   CC_API_BEGIN
   CC_CHECK(h && size, "null argument");
-  CC_CHECK(dtype >= 0 && dtype <= 2, "dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+  CC_CHECK(dtype >= 0 && dtype <= 3, "dtype must be 0 (f32), 1 (f16), 2 (bf16) or 3 (f16 storage with split f16 weights)");
   CC_CHECK(res > 0 && res % 32 == 0, "res must be a positive multiple of 32");
   const Arch* a = nullptr;
   for (const Arch& x : kArch) if (!strcmp(x.size, size)) a = &x;
@@ -939,7 +963,7 @@ int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device
   CC_CHECK(n > 0 && device >= 0 && device < n, "no such HIP device");
   CC_HIP(hipSetDevice(device));
   std::unique_ptr<cc_yolo> y(new cc_yolo());
-  y->arch = a; y->res = res; y->dtype = dtype; y->device = device;
+  y->arch = a; y->res = res; y->dtype = storage_dtype(dtype); y->wsplit = dtype == F16S; y->device = device;
   CC_HIP(hipStreamCreateWithFlags(&y->stream, hipStreamNonBlocking));
   CC_HIP(hipEventCreate(&y->ev0)); CC_HIP(hipEventCreate(&y->ev1));
   *h = y.release();
@@ -1270,11 +1294,14 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
   w.shape = {Cout, Cin / groups, k, k};
   w.data.assign(w_oihw, w_oihw + (size_t)Cout * (Cin / groups) * k * k);
   if (bias) { b.shape = {Cout}; b.data.assign(bias, bias + Cout); }
-  PackedConv pc = pack_convs(dtype, {&w}, {bias ? &b : nullptr}, {groups}, 0);
+  const int split = dtype == F16S;                       // dtype 3: f16 storage, split weights
+  dtype = storage_dtype(dtype);
+  PackedConv pc = pack_convs(dtype, {&w}, {bias ? &b : nullptr}, {groups}, 0, split);
   ConvP c{};
   c.s0 = Src{x_dev, H, W, Cin, 0, Cin, 0}; c.s1 = Src{x_dev, 1, 1, 0, 0, 0, 0};
   c.B = B; c.Hin = H; c.Win = W; c.Cin = Cin; c.ks = k; c.stride = stride; c.pad = k / 2;
-  c.Ho = (H + 2 * c.pad - k) / stride + 1; c.Wo = (W + 2 * c.pad - k) / stride + 1; c.Cout = Cout; c.Ktot = k * k * Cin; c.Kw = pc.kw;
+  c.Ho = (H + 2 * c.pad - k) / stride + 1; c.Wo = (W + 2 * c.pad - k) / stride + 1; c.Cout = Cout; c.Ktot = k * k * Cin * (1 + split); c.Kw = pc.kw;
+  c.split = pc.split; c.oscale = pc.oscale;
   c.w = pc.w; c.bias = pc.bias; c.out = out_dev; c.out_cstride = Cout; c.out_coff = 0; c.out_f32 = 0; c.res = nullptr; c.act = act;
   c.variant = force_direct;                              // 0 auto, 1 direct, 2 generic MFMA, 3 halo-resident, 4 weights-stationary
   if (force_direct == 1) launch_conv_direct(dtype, c, (hipStream_t)stream); else launch_conv(dtype, c, (hipStream_t)stream);
@@ -1295,7 +1322,9 @@ int cc_dev_set(const char* key, int value) {
 // on a private stream around `iters` back-to-back launches after 3 warm-up launches.  variant as ConvP::variant.
 int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int variant, int iters, float* ms) {
   CC_API_BEGIN
-  CC_CHECK(ms && iters > 0 && (dtype == F16 || dtype == BF16), "bad argument");
+  CC_CHECK(ms && iters > 0 && (dtype == F16 || dtype == BF16 || dtype == F16S), "bad argument");
+  const int split = dtype == F16S;
+  dtype = storage_dtype(dtype);
   HostTensor w, b;
   w.shape = {Cout, Cin, k, k};
   w.data.resize((size_t)Cout * Cin * k * k);
@@ -1304,7 +1333,7 @@ int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int 
   const float sc = 2.0f / sqrtf((float)Cin * k * k);
   for (auto& v : w.data) v = rnd() * sc;
   b.shape = {Cout}; b.data.assign(Cout, 0.01f);
-  PackedConv pc = pack_convs(dtype, {&w}, {&b}, {1}, 0);
+  PackedConv pc = pack_convs(dtype, {&w}, {&b}, {1}, 0, split);
   const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * Ho * Wo * Cout;
   std::vector<float> hx(std::min<size_t>(nin, (size_t)1 << 24));
@@ -1317,7 +1346,7 @@ int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int 
   ConvP c{};
   c.s0 = Src{x, H, W, Cin, 0, Cin, 0}; c.s1 = Src{x, 1, 1, 0, 0, 0, 0};
   c.B = B; c.Hin = H; c.Win = W; c.Cin = Cin; c.ks = k; c.stride = stride; c.pad = pad; c.Ho = Ho; c.Wo = Wo; c.Cout = Cout;
-  c.Ktot = k * k * Cin; c.Kw = pc.kw; c.w = pc.w; c.bias = pc.bias; c.out = out; c.out_cstride = Cout; c.act = act; c.variant = variant;
+  c.Ktot = k * k * Cin * (1 + split); c.Kw = pc.kw; c.split = pc.split; c.oscale = pc.oscale; c.w = pc.w; c.bias = pc.bias; c.out = out; c.out_cstride = Cout; c.act = act; c.variant = variant;
   hipStream_t s; CC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   hipEvent_t e0, e1; CC_HIP(hipEventCreate(&e0)); CC_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) launch_conv(dtype, c, s);

@@ -19,7 +19,10 @@ from .arch import YOLO_ARCH
 from .helpers import Tensor, as_numpy
 from .weights import load_safetensors
 
-DTYPES = {"f32": 0, "float32": 0, "f16": 1, "float16": 1, "half": 1, "bf16": 2, "bfloat16": 2}
+# "f16s": f16 activations with every conv weight carried as two f16 planes (W = W_hi + W_lo, ~22 significant bits, f32 accumulation):
+# the 16-bit mode whose detections stay within the reference tolerance for ANY float32 checkpoint (plain f16 / bf16 round the weights
+# to 11 / 8 bits: speed modes).  "f32" is the exact-arithmetic parity mode.
+DTYPES = {"f32": 0, "float32": 0, "f16": 1, "float16": 1, "half": 1, "bf16": 2, "bfloat16": 2, "f16s": 3, "f16_split": 3}
 MAX_DET = 300
 
 
