@@ -326,10 +326,9 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(const AttnP p) {
 
 template <class T, int NF> static void launch_attn_mfma(const AttnP& p, hipStream_t stream) {
   const size_t lds = (size_t)NF * 16 * 128 + (size_t)64 * (NF * 16 + 16) * sizeof(T);
-  static bool configured = false;
-  if (!configured) {
+  static PerDevice once;                               // the attribute is per device (common.h)
+  if (once.first(once.index())) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<T, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   hipLaunchKernelGGL((attn_mfma_kernel<T, NF>), dim3(1, p.H, p.B), dim3(256), lds, stream, p);
 }

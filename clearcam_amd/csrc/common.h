@@ -120,6 +120,22 @@ struct ConvP {
   int variant;                   // kernel choice: 0 auto; tests force 1 direct, 2 generic MFMA, 3 halo-resident 3x3, 4 weights-stationary 3x3, 5 single-barrier schedule with 256x256 tiles, 6 the same with 128x128 tiles, 7 eight-wave two-group 256x256 kernel, 8 wave-autonomous narrow 3x3, 9 few-tile configuration (narrow channel tiles, 3-4 LDS stages)
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are per DEVICE: a launcher's one-time set-up is keyed by the current
+// device ordinal (a process may hold handles on several GPUs), not by a process-wide flag.
+struct PerDevice {
+  bool done[64] = {}; int cus[64] = {};
+  int index() const { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = -1; return d; }
+  // true once per device (always true for an ordinal outside the table: the set-up is idempotent)
+  bool first(int d) { if (d < 0) return true; const bool f = !done[d]; done[d] = true; return f; }
+  int cu_count(int d) {
+    if (d >= 0 && cus[d]) return cus[d];
+    int dev = 0; hipDeviceProp_t pr;
+    CC_HIP(hipGetDevice(&dev)); CC_HIP(hipGetDeviceProperties(&pr, dev));
+    if (d >= 0) cus[d] = pr.multiProcessorCount;
+    return pr.multiProcessorCount;
+  }
+};
+
 // Plan cache of a model handle: one plan (buffers + captured hipGraph) per input shape, bounded.  A service that sees many
 // batch sizes would otherwise keep a multi-GB arena for each of them forever.  At most cap() plans live at once
 // (CLEARCAM_MAX_PLANS, default 16); inserting into a full cache drains the handle's stream and drops the least recently

@@ -171,10 +171,9 @@ bool conv_adown_supported(int dt, const ConvP& p) {
 
 template <class T, int BN> static void launch_adown_k(const ConvP& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * (128 + BN) * 8 * 16;
-  static bool configured = false;
-  if (!configured) {
+  static PerDevice once;                               // the attribute is per device (common.h)
+  if (once.first(once.index())) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_avg_s2_kernel<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   const int M = p.B * p.Ho * p.Wo;
   ConvAux a{};

@@ -641,11 +641,10 @@ static int g_cfg[4] = {-1, 0, 0, 0};
 template <class T, int BM, int BN, int WM, bool SIMPLE, int CPRW, int NS>
 static void launch_k(const ConvP& p, const ConvAux& a, int mtiles, hipStream_t stream) {
   constexpr size_t lds = (size_t)NS * (BM + BN) * CPRW * 16;
-  static bool configured = false;
-  if (!configured) {
+  static PerDevice once;                               // the attribute is per device (common.h)
+  if (once.first(once.index())) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   hipLaunchKernelGGL((conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>), dim3(mtiles * a.nt), dim3(2 * BM), lds, stream, p, a);
 }
@@ -672,10 +671,9 @@ static void launch_cfg(const ConvP& p, const ConvAux& a, int M, int bm, int ns, 
 
 template <class T, int TS> static void launch_big(const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * (2 * TS) * 8 * 16;
-  static bool configured = false;
-  if (!configured) {
+  static PerDevice once;                               // the attribute is per device (common.h)
+  if (once.first(once.index())) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<T, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   hipLaunchKernelGGL((conv_big_kernel<T, TS>), dim3(((M + TS - 1) / TS) * a.nt), dim3(256), lds, stream, p, a);
 }
@@ -717,10 +715,9 @@ template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const Conv
 
 template <class T, int BN> static void launch_halo(const ConvP& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)(2 * 184 * 8 + 2 * BN * 8) * 16;
-  static bool configured = false;
-  if (!configured) {
+  static PerDevice once;                               // the attribute is per device (common.h)
+  if (once.first(once.index())) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   HaloAux a{};
   a.tx = (p.Wo + 15) / 16; a.tiles = ((p.Ho + 7) / 8) * a.tx; a.nt = (p.Cout + BN - 1) / BN;
@@ -750,13 +747,11 @@ template <class T, int CIN, int COUT> static void launch_ws(const ConvP& p, hipS
   constexpr int CPRW = CIN / 8, RPP = 256 / CPRW;
   constexpr int XP = (180 + RPP - 1) / RPP * RPP * CPRW, WL = (9 * COUT + RPP - 1) / RPP * RPP * CPRW;
   constexpr size_t lds = (size_t)(WL + 2 * XP + 128 * COUT * 2 / 16) * 16;
-  static int cus = 0;
-  if (!cus) {
+  static PerDevice pd;                                 // attribute and CU count per device ordinal (common.h)
+  const int pdi = pd.index();
+  if (pd.first(pdi))
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<T, CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0; hipDeviceProp_t pr;
-    CC_HIP(hipGetDevice(&dev)); CC_HIP(hipGetDeviceProperties(&pr, dev));
-    cus = pr.multiProcessorCount;
-  }
+  const int cus = pd.cu_count(pdi);
   WsAux a{};
   a.tx = (p.Wo + 15) / 16; a.tiles = ((p.Ho + 7) / 8) * a.tx; a.total = p.B * a.tiles;
   a.inv_tiles = 1.0f / (float)a.tiles; a.inv_tx = 1.0f / (float)a.tx;

@@ -535,15 +535,11 @@ bool conv_persist_ok(const ConvP& p) {
 
 template <class T, int MM, int ABL = 0> static void launch_persist_t(const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * 512 * 8 * 16 + 512 * 4 * 16;     // two K tiles of (256 + 256) rows x 128 bytes + the per-row loader table
-  static bool configured = false;
-  static int cus = 0;
-  if (!configured) {
+  static PerDevice pd;                                 // attribute and CU count per device ordinal
+  const int d = pd.index();
+  if (pd.first(d))
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_persist_kernel<T, MM, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0; hipDeviceProp_t pr;
-    CC_HIP(hipGetDevice(&dev)); CC_HIP(hipGetDeviceProperties(&pr, dev));
-    cus = pr.multiProcessorCount;
-    configured = true;
-  }
+  const int cus = pd.cu_count(d);
   ConvAux b = a;
   b.ntiles = ((M + 255) / 256) * a.nt;
   hipLaunchKernelGGL((conv_persist_kernel<T, MM, ABL>), dim3(std::min(b.ntiles, cus)), dim3(512), lds, stream, p, b);

@@ -302,12 +302,11 @@ int g_phase_flags_override = -1;                       // cc_dev_set("phase_flag
 
 template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * 512 * 8 * 16 + 512 * 4 * 16;     // two K tiles of (256 + 256) rows x 128 bytes + the per-row loader table
-  static bool configured = false;
-  if (!configured) {
+  static PerDevice once;                               // the attribute is per device (common.h)
+  if (once.first(once.index())) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_phase_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   static int env_flags = -2;
   // CLEARCAM_PHASE_FLAGS: unset = the default rule below; 32: schedule 1 one tile per block; 0: schedule 0; 8 / 16: timing ablations of

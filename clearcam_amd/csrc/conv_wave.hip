@@ -146,13 +146,11 @@ template <class T, int CIN, int COUT, int NW> static void launch_wave(const Conv
   constexpr int CPRW = CIN / 8, ROWB = CIN * 2, RPI = 64 / CPRW, NPI = (72 + RPI - 1) / RPI;
   constexpr int RPP = NW * 64 / CPRW, WPASS = (9 * COUT + RPP - 1) / RPP;
   constexpr size_t lds = (size_t)WPASS * RPP * ROWB + (size_t)NW * NPI * RPI * ROWB;
-  static int cus = 0;
-  if (!cus) {
+  static PerDevice pd;                                 // attribute and CU count per device ordinal (common.h)
+  const int pdi = pd.index();
+  if (pd.first(pdi))
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wave_kernel<T, CIN, COUT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0; hipDeviceProp_t pr;
-    CC_HIP(hipGetDevice(&dev)); CC_HIP(hipGetDeviceProperties(&pr, dev));
-    cus = pr.multiProcessorCount;
-  }
+  const int cus = pd.cu_count(pdi);
   WaveAux a{};
   a.tx = (p.Wo + 15) / 16; a.tiles = ((p.Ho + 1) / 2) * a.tx; a.total = p.B * a.tiles;
   a.inv_tiles = 1.0f / (float)a.tiles; a.inv_tx = 1.0f / (float)a.tx;

@@ -410,13 +410,11 @@ bool csp_fused_supported(int dt, int hid) { return (dt == F16 || dt == BF16) && 
 
 template <class T, int HID, bool RES> static void launch_csp(const CspP& p, hipStream_t stream) {
   constexpr int lds = RES ? CspGeom<HID>::R_LDS_BYTES : CspGeom<HID>::S_LDS_BYTES;
-  static int cus = 0;
-  if (!cus) {
+  static PerDevice pd;                                 // attribute and CU count per device ordinal (common.h)
+  const int pdi = pd.index();
+  if (pd.first(pdi))
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csp_fused_kernel<T, HID, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    int dev = 0; hipDeviceProp_t pr;
-    CC_HIP(hipGetDevice(&dev)); CC_HIP(hipGetDeviceProperties(&pr, dev));
-    cus = pr.multiProcessorCount;
-  }
+  const int cus = pd.cu_count(pdi);
   const int total = p.B * p.tiles;
   // persistent: one block per CU, a multiple of 8 so that every XCD gets the same number of walkers
   const int grid = RES ? std::max(8, std::min(cus, total) & ~7) : total;

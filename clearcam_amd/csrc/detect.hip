@@ -7,6 +7,7 @@
 //                scale_boxes/clip_boxes              detection/yolov9.py:406-458
 // Integer/byte work (the uint8 resize) is bit-exact against the oracle; float work follows the
 // reference's operation order in f32.
+#include <type_traits>
 #include "kernels.h"
 #include "mfma.h"
 
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreP p) {
 // BIG: 36 KB of scratch for the source-byte stage (camera frames scaled down by up to ~3x: 1080p -> 384x640); otherwise 18 KB, which
 // is what the output stage needs (each wave passes its 64 pixels through its own 32-pixel area in two halves) and lets six blocks
 // share a CU instead of three.
-template <class T, int COUT, bool BIG>
+// SPLIT: the weights are two f16 planes (ConvP::split): a second MFMA per channel fragment on the low plane, the accumulator scaled by the
+// exact 2^-e in the epilogue.
+template <class T, int COUT, bool BIG, bool SPLIT = false>
 __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
   constexpr int PW = 33, PROW = 104;                     // patch row: 33 pixels x 3 channels (+ pad) in storage type
   constexpr int NT = COUT / 16, OROW = COUT + 8;         // staged output row: COUT channels + 16 bytes (bank spread)
@@ -104,9 +107,14 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
 
   // weights: A operand, row = output channel, this lane's eight k values = one 16-byte load; kept in registers for the tile
   const int kg = lane >> 4, row = lane & 15;
-  uint4 afrag[NT];
+  uint4 afrag[NT], alo[SPLIT ? NT : 1];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) afrag[nt] = reinterpret_cast<const uint4*>(p.w)[(nt * 16 + row) * 4 + kg];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) alo[nt] = reinterpret_cast<const uint4*>(p.w_lo)[(nt * 16 + row) * 4 + kg];
+  }
+  const float osc = SPLIT ? p.oscale : 1.0f;
 
   // ---- phase 1: the 33x33 letterboxed pixels of this tile -> patch ------------------------------------------------
   // Per-pixel byte loads from HBM are what bounds the stand-alone letterbox kernel (12 load instructions per pixel), so the
@@ -252,10 +260,11 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
     for (int nt = 0; nt < NT; ++nt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       Mma<T>::run(afrag[nt], bfrag, acc);
+      if constexpr (SPLIT) Mma<T>::run(alo[nt], bfrag, acc);
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float xv = acc[i] + bias[nt][i];
+        const float xv = __builtin_fmaf(acc[i], osc, bias[nt][i]);
         o[i] = (p.abl & 2) ? xv : xv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xv * -1.4426950408889634f));   // SiLU, as conv_mfma's 16-bit epilogue
       }
       *reinterpret_cast<uint2*>(wstage + ((rr & 1) * 16 + tx) * OROW + nt * 16 + kg * 4) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
@@ -276,20 +285,20 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
 }
 
 template <class T>
-__global__ void stem_pack_kernel(const T* __restrict__ w, int w_row, int cin_pad, int n, T* __restrict__ out) {
+__global__ void stem_pack_kernel(const T* __restrict__ w, int w_row, int tap_stride, int plane_off, int n, T* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n * 32) return;
   // k slot -> (row r, element q = s*3 + c): slots 0..23 = rows 0..2 x elements 0..7, slots 24..26 = element 8 of rows 0..2
   const int co = i >> 5, k = i & 31, g = k >> 3, e = k & 7;
   const bool live = g < 3 || e < 3;
   const int r = g < 3 ? g : min(e, 2), q = g < 3 ? e : 8, s = q / 3, c = q - s * 3;
-  out[i] = live ? w[(size_t)co * w_row + (r * 3 + s) * cin_pad + c] : from_f32<T>(0.f);
+  out[i] = live ? w[(size_t)co * w_row + (r * 3 + s) * tap_stride + plane_off + c] : from_f32<T>(0.f);
 }
 
-void stem_pack_weights(int dt, const void* w_packed, int w_row, int cin_pad, int Cout, void* out, hipStream_t stream) {
+void stem_pack_weights(int dt, const void* w_packed, int w_row, int tap_stride, int plane_off, int Cout, void* out, hipStream_t stream) {
   const dim3 grid((Cout * 32 + 255) / 256), block(256);
-  if (dt == F16) hipLaunchKernelGGL(stem_pack_kernel<f16_t>, grid, block, 0, stream, (const f16_t*)w_packed, w_row, cin_pad, Cout, (f16_t*)out);
-  else hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)w_packed, w_row, cin_pad, Cout, (bf16_t*)out);
+  if (dt == F16) hipLaunchKernelGGL(stem_pack_kernel<f16_t>, grid, block, 0, stream, (const f16_t*)w_packed, w_row, tap_stride, plane_off, Cout, (f16_t*)out);
+  else hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)w_packed, w_row, tap_stride, plane_off, Cout, (bf16_t*)out);
   CC_HIP(hipGetLastError());
 }
 
@@ -297,6 +306,14 @@ bool stem_fused_supported(int dt, int Cout) { return dt != F32 && (Cout == 16 ||
 
 template <class T, bool BIG> static void launch_stem_b(const StemP& p, hipStream_t stream) {
   const dim3 grid((unsigned)((p.Wo + 15) / 16), (unsigned)((p.Ho + 15) / 16), (unsigned)p.pre.B), block(256);
+  if constexpr (std::is_same<T, f16_t>::value) {
+    if (p.w_lo) {                                                     // split weights (f16 storage only)
+      if (p.Cout == 64) hipLaunchKernelGGL((stem_fused_kernel<T, 64, BIG, true>), grid, block, 0, stream, p);
+      else if (p.Cout == 32) hipLaunchKernelGGL((stem_fused_kernel<T, 32, BIG, true>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((stem_fused_kernel<T, 16, BIG, true>), grid, block, 0, stream, p);
+      return;
+    }
+  }
   if (p.Cout == 64) hipLaunchKernelGGL((stem_fused_kernel<T, 64, BIG>), grid, block, 0, stream, p);
   else if (p.Cout == 32) hipLaunchKernelGGL((stem_fused_kernel<T, 32, BIG>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((stem_fused_kernel<T, 16, BIG>), grid, block, 0, stream, p);
@@ -313,7 +330,7 @@ template <class T> static void launch_stem_t(const StemP& p, hipStream_t stream)
 void launch_stem_fused(int dt, const StemP& p0, hipStream_t stream) {
   StemP p = p0;
   { static const int abl = [] { const char* e = getenv("CLEARCAM_STEM_ABL"); return e ? atoi(e) : 0; }(); p.abl = abl; }
-  CC_CHECK(stem_fused_supported(dt, p.Cout) && p.out_coff % 8 == 0 && p.out_cstride % 8 == 0, "fused stem: unsupported dtype / channel count");
+  CC_CHECK(stem_fused_supported(dt, p.Cout) && p.out_coff % 8 == 0 && p.out_cstride % 8 == 0 && (!p.w_lo || dt == F16), "fused stem: unsupported dtype / channel count");
   if (dt == F16) launch_stem_t<f16_t>(p, stream); else launch_stem_t<bf16_t>(p, stream);
   CC_HIP(hipGetLastError());
 }
@@ -402,9 +419,12 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
 //                 pixel (ties -> lower class index = decode_kernel's first-maximum scan)
 //   box:          the 64 box logits of a pixel go through LDS so that lane (pixel, side) runs decode_kernel's own 16-bin sequence
 constexpr int kTailTPB = 8;            // 64-pixel tiles per block
-template <class T, int CH>
+// SPLIT: weight rows are [hi(Cin) | lo(Cin)] (ConvP::split): the K walk passes the pixel fragments twice, high plane first - the order of
+// the conv kernels' virtual taps - and the accumulator is scaled by the level's exact 2^-e before the bias.
+template <class T, int CH, bool SPLIT = false>
 __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int blk1, int blk2) {
-  constexpr int KC3 = CH / 32, ROW3 = CH * 2 + 16, ROW2 = 64 * 2 + 16, LROW = 68;      // LDS row strides: bytes, bytes, floats
+  constexpr int PL = SPLIT ? 2 : 1;
+  constexpr int KC3 = CH / 32, ROW3 = PL * CH * 2 + 16, ROW2 = PL * 64 * 2 + 16, LROW = 68;      // LDS row strides: bytes, bytes, floats
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* w3s = smem;                                    // 80 rows x ROW3
   char* w2s = smem + 80 * ROW3;                        // 64 rows x ROW2
@@ -419,13 +439,13 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int b
   // weights -> LDS (16-byte chunks; rows are kw elements apart in global memory)
   {
     const char* g3 = reinterpret_cast<const char*>(p.w3[lvl]);
-    for (int c = tid; c < 80 * (CH / 8); c += 256) {
-      const int row = c / (CH / 8), ch = c - row * (CH / 8);
+    for (int c = tid; c < 80 * (PL * CH / 8); c += 256) {
+      const int row = c / (PL * CH / 8), ch = c - row * (PL * CH / 8);
       *reinterpret_cast<uint4*>(w3s + row * ROW3 + ch * 16) = *reinterpret_cast<const uint4*>(g3 + ((size_t)row * p.kw3 + ch * 8) * sizeof(T));
     }
     const char* g2 = reinterpret_cast<const char*>(p.w2[lvl]);
-    for (int c = tid; c < 64 * 8; c += 256) {
-      const int row = c >> 3, ch = c & 7;
+    for (int c = tid; c < 64 * 8 * PL; c += 256) {
+      const int row = c / (8 * PL), ch = c - row * (8 * PL);
       *reinterpret_cast<uint4*>(w2s + row * ROW2 + ch * 16) = *reinterpret_cast<const uint4*>(g2 + ((size_t)row * p.kw2 + ch * 8) * sizeof(T));
     }
   }
@@ -437,6 +457,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int b
   for (int j = 0; j < 4; ++j) b2v[j] = *reinterpret_cast<const float4*>(p.b2[lvl] + j * 16 + fg * 4);
 #pragma unroll
   for (int j = 0; j < 5; ++j) b3v[j] = *reinterpret_cast<const float4*>(p.b3[lvl] + j * 16 + fg * 4);
+  const float os2 = SPLIT ? p.os2[lvl] : 1.0f, os3 = SPLIT ? p.os3[lvl] : 1.0f;
   __syncthreads();
   const T* bxp = reinterpret_cast<const T*>(p.bx[lvl]);
   const T* clp = reinterpret_cast<const T*>(p.cl[lvl]);
@@ -463,8 +484,9 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int b
     for (int j = 0; j < 4; ++j) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kc = 0; kc < 2; ++kc) Mma<T>::run(*reinterpret_cast<const uint4*>(w2s + (j * 16 + fr) * ROW2 + (kc * 4 + fg) * 16), xb[kc], acc);
-      *reinterpret_cast<float4*>(lgw + fr * LROW + j * 16 + fg * 4) = make_float4(acc[0] + b2v[j].x, acc[1] + b2v[j].y, acc[2] + b2v[j].z, acc[3] + b2v[j].w);
+      for (int kc = 0; kc < 2 * PL; ++kc) Mma<T>::run(*reinterpret_cast<const uint4*>(w2s + (j * 16 + fr) * ROW2 + (kc * 4 + fg) * 16), xb[kc & 1], acc);
+      *reinterpret_cast<float4*>(lgw + fr * LROW + j * 16 + fg * 4) = make_float4(__builtin_fmaf(acc[0], os2, b2v[j].x), __builtin_fmaf(acc[1], os2, b2v[j].y),
+                                                                                  __builtin_fmaf(acc[2], os2, b2v[j].z), __builtin_fmaf(acc[3], os2, b2v[j].w));
     }
     // ---- class branch: sigmoid + max in registers ---------------------------------------------------------------------------
     float best = -1.f; int bi = 0;
@@ -472,8 +494,8 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int b
     for (int j = 0; j < 5; ++j) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kc = 0; kc < KC3; ++kc) Mma<T>::run(*reinterpret_cast<const uint4*>(w3s + (j * 16 + fr) * ROW3 + (kc * 4 + fg) * 16), xc[kc], acc);
-      const float l[4] = {acc[0] + b3v[j].x, acc[1] + b3v[j].y, acc[2] + b3v[j].z, acc[3] + b3v[j].w};
+      for (int kc = 0; kc < KC3 * PL; ++kc) Mma<T>::run(*reinterpret_cast<const uint4*>(w3s + (j * 16 + fr) * ROW3 + (kc * 4 + fg) * 16), xc[kc % KC3], acc);
+      const float l[4] = {__builtin_fmaf(acc[0], os3, b3v[j].x), __builtin_fmaf(acc[1], os3, b3v[j].y), __builtin_fmaf(acc[2], os3, b3v[j].z), __builtin_fmaf(acc[3], os3, b3v[j].w)};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float sg = class_sigmoid(l[e]);
@@ -514,19 +536,24 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int b
   }
 }
 
-bool head_tail_supported(int dt, int ch) { return dt != F32 && (ch == 128 || ch == 256); }
+bool head_tail_supported(int dt, int ch, int split) { return dt != F32 && (ch == 128 || ch == 256) && (!split || dt == F16); }
 
-template <class T, int CH> static void launch_head_tail_t(const HeadTailP& p, hipStream_t stream) {
-  constexpr size_t lds = (size_t)80 * (CH * 2 + 16) + 64 * (64 * 2 + 16) + 4 * 16 * 68 * 4;
-  static bool configured = false;
-  if (!configured) { CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_tail_kernel<T, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); configured = true; }
+template <class T, int CH, bool SPLIT = false> static void launch_head_tail_t(const HeadTailP& p, hipStream_t stream) {
+  constexpr int PL = SPLIT ? 2 : 1;
+  constexpr size_t lds = (size_t)80 * (PL * CH * 2 + 16) + 64 * (PL * 64 * 2 + 16) + 4 * 16 * 68 * 4;
+  static_assert(lds <= 160 * 1024, "the level's weights must fit in LDS");
+  // (per device: a process may hold handles on several GPUs, and the attribute is per device)
+  static PerDevice once;
+  if (once.first(once.index()))
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_tail_kernel<T, CH, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int nb[3];
   for (int l = 0; l < 3; ++l) { const long M = (long)p.B * p.H[l] * p.W[l]; nb[l] = (int)((M + 64 * kTailTPB - 1) / (64 * kTailTPB)); }
-  hipLaunchKernelGGL((head_tail_kernel<T, CH>), dim3(nb[0] + nb[1] + nb[2]), dim3(256), lds, stream, p, nb[0], nb[0] + nb[1]);
+  hipLaunchKernelGGL((head_tail_kernel<T, CH, SPLIT>), dim3(nb[0] + nb[1] + nb[2]), dim3(256), lds, stream, p, nb[0], nb[0] + nb[1]);
 }
 
 void launch_head_tail(int dt, const HeadTailP& p, hipStream_t stream) {
-  CC_CHECK(head_tail_supported(dt, p.ch) && p.kw2 >= 64 && p.kw3 >= p.ch, "fused DDetect tail: unsupported dtype / class-branch width");
+  CC_CHECK(head_tail_supported(dt, p.ch, p.split) && p.kw2 >= 64 * (1 + p.split) && p.kw3 >= p.ch * (1 + p.split), "fused DDetect tail: unsupported dtype / class-branch width");
+  if (p.split) { if (p.ch == 256) launch_head_tail_t<f16_t, 256, true>(p, stream); else launch_head_tail_t<f16_t, 128, true>(p, stream); CC_HIP(hipGetLastError()); return; }
   if (dt == F16) { if (p.ch == 256) launch_head_tail_t<f16_t, 256>(p, stream); else launch_head_tail_t<f16_t, 128>(p, stream); }
   else { if (p.ch == 256) launch_head_tail_t<bf16_t, 256>(p, stream); else launch_head_tail_t<bf16_t, 128>(p, stream); }
   CC_HIP(hipGetLastError());

@@ -74,14 +74,16 @@ void launch_preprocess(int dt, const PreP& p, hipStream_t stream);
 struct StemP {
   PreP pre;                               // pre.out / pre.out_c unused
   const void* w; const float* bias;       // [Cout][32] storage dtype from stem_pack_weights (k = r*9 + s*3 + c, zero for k >= 27), bias f32
+  const void* w_lo; float oscale;         // split weights (ConvP::split): the low plane in the same layout and the exact 2^-e output scale; null / ignored otherwise
   int Cout;                               // 16, 32 or 64
   void* out; int out_cstride, out_coff;   // (B,Ho,Wo,out_cstride) storage dtype
   int Ho, Wo;                             // Hn/2, Wn/2
   int abl;                                // timing ablation bits (development only; 0 in production)
 };
 bool stem_fused_supported(int dt, int Cout);
-// reorder the generic conv's packed weights [Cout][w_row] (k = (r*3+s)*cin_pad + c) into the fused kernel's [Cout][32] rows
-void stem_pack_weights(int dt, const void* w_packed, int w_row, int cin_pad, int Cout, void* out, hipStream_t stream);
+// reorder the generic conv's packed weights [Cout][w_row] (k = (r*3+s)*tap_stride + plane_off + c; plain: tap_stride = cin_pad, plane_off = 0;
+// split: tap_stride = 2*cin_pad, plane_off = 0 / cin_pad for the high / low plane) into the fused kernel's [Cout][32] rows
+void stem_pack_weights(int dt, const void* w_packed, int w_row, int tap_stride, int plane_off, int Cout, void* out, hipStream_t stream);
 void launch_stem_fused(int dt, const StemP& p, hipStream_t stream);
 // tinygrad `interpolate(mode='linear', align_corners=False)` index tables for one axis, evaluated in float32 (yolo.hip)
 void axis_tables(int n_in, int n_out, std::vector<int>& lo, std::vector<int>& hi, std::vector<float>& fr);
@@ -105,11 +107,12 @@ struct HeadTailP {
   const float* b2[3]; const float* b3[3];
   int H[3], W[3];
   int kw2, kw3, ch;
+  int split; float os2[3], os3[3];        // split weights: rows are [hi(Cin) | lo(Cin)], os2 / os3 the exact 2^-e output scales per level
   int B, A;
   const float* dfl_w; float conf;
   float* det;                             // (B,A,6)
 };
-bool head_tail_supported(int dt, int ch);
+bool head_tail_supported(int dt, int ch, int split = 0);
 void launch_head_tail(int dt, const HeadTailP& p, hipStream_t stream);
 // batches in flight (yolo.hip): streams for the extra slots of a handle, probed until kernels on them overlap with `base` and each other
 bool streams_overlap(hipStream_t a, hipStream_t b);

@@ -275,16 +275,17 @@ struct Builder {
   // The detector's first conv straight from the frames (stem_fused_kernel); 16-bit storage only, CLEARCAM_FUSE_STEM=0 disables.
   bool fuse_stem(int cout) const {
     static const bool on = [] { const char* e = getenv("CLEARCAM_FUSE_STEM"); return e ? atoi(e) != 0 : true; }();
-    return on && !Y->wsplit && Y->cin_pad() == 8 && stem_fused_supported(Y->dtype, cout);
+    return on && Y->cin_pad() == 8 && stem_fused_supported(Y->dtype, cout);
   }
-  // the fused kernel's weight layout ([Cout][32], k = r*9 + s*3 + c), derived once per handle from the packed conv weights
-  const void* stem_weights(const std::string& name, const PackedConv& pc) {
-    const std::string key = name + "#stem";
+  // the fused kernel's weight layout ([Cout][32], k = r*9 + s*3 + c), derived once per handle from the packed conv weights; split
+  // weights: one such matrix per plane (plane 1 = the low plane)
+  const void* stem_weights(const std::string& name, const PackedConv& pc, int plane = 0) {
+    const std::string key = name + (plane ? "#stem_lo" : "#stem");
     auto it = Y->packed.find(key);
     if (it != Y->packed.end()) return it->second.w;
     PackedConv f; f.cout = pc.cout;
     CC_HIP(hipMalloc(&f.w, (size_t)pc.cout * 32 * dtype_size(Y->dtype) + 256));
-    stem_pack_weights(Y->dtype, pc.w, pc.kw, 8, pc.cout, f.w, Y->stream);
+    stem_pack_weights(Y->dtype, pc.w, pc.kw, pc.split ? 16 : 8, plane ? 8 : 0, pc.cout, f.w, Y->stream);
     CC_HIP(hipStreamSynchronize(Y->stream));
     return (Y->packed[key] = f).w;
   }
@@ -298,6 +299,7 @@ struct Builder {
     pp.xlo = P->xlo; pp.xhi = P->xhi; pp.xfr = P->xfr; pp.ylo = P->ylo; pp.yhi = P->yhi; pp.yfr = P->yfr;
     pp.flip = 1; pp.div = 255.0f; pp.sub = 0.0f; pp.pad_val = 0.0f;            // as cc_yolo_detect's preprocess launch
     q.w = stem_weights(name, pc); q.bias = pc.bias; q.Cout = pc.cout;
+    q.w_lo = pc.split ? stem_weights(name, pc, 1) : nullptr; q.oscale = pc.oscale;
     q.out = (void*)(intptr_t)out.buf; q.out_cstride = ob.C; q.out_coff = out.coff; q.Ho = ob.H; q.Wo = ob.W;
     op.alg_macs = (double)P->B * ob.H * ob.W * pc.macs_px;
     push(op, {wr(out)});
@@ -491,7 +493,7 @@ struct Builder {
   // level + decode_kernel (and with them the "raw<l>" parity taps, which the f32 mode always has).
   bool fuse_head_tail() const {
     const char* e = getenv("CLEARCAM_FUSE_HEAD");
-    return (!e || atoi(e) != 0) && !Y->wsplit && head_tail_supported(Y->dtype, a.cls_hidden);
+    return (!e || atoi(e) != 0) && head_tail_supported(Y->dtype, a.cls_hidden, Y->wsplit);
   }
   // One level of DDetect (:157-220): the level's conv chain runs on its own lane - it only needs that level's feature map, so
   // P3's 1.3 ms of 3x3 convs overlap the neck's way down to P4 / P5 (whose 40x40 / 20x20 launches leave CUs idle) instead of queueing
@@ -515,6 +517,7 @@ struct Builder {
       HeadTailP& q = head_tail.tail;
       q.bx[l] = (const void*)(intptr_t)bxb; q.cl[l] = (const void*)(intptr_t)clb;
       q.w2[l] = c2.w; q.w3[l] = c3.w; q.b2[l] = c2.bias; q.b3[l] = c3.bias; q.kw2 = c2.kw; q.kw3 = c3.kw;
+      q.split = c2.split; q.os2[l] = c2.oscale; q.os3[l] = c3.oscale;
       q.H[l] = H; q.W[l] = W;
       head_acc.push_back(rd(whole(bxb))); head_acc.push_back(rd(whole(clb)));
     } else {

@@ -600,11 +600,118 @@ def test_persistent_eight_wave_kernel_matches_torch(case, dtype):
         lib_.check(L.cc_dev_set(b"phase_flags", -1))
 
 
+_STEM_SCRIPT = r"""
+import sys, numpy as np
+from clearcam_amd.weights import synthetic_yolov9_state_dict
+from clearcam_amd.yolov9 import YOLOv9
+size, res, dtype, H, W, f32 = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+frames = np.random.default_rng(5).integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+if f32: frames = frames.astype(np.float32)
+m = YOLOv9(size, res, state_dict=synthetic_yolov9_state_dict(size, 1234), dtype=dtype, device=0)
+if len(sys.argv) > 8:                                  # device frames that start at an odd byte address
+    import torch
+    raw = torch.zeros(frames.size + 8, dtype=torch.uint8, device="cuda")
+    off = int(sys.argv[8])
+    raw[off:off + frames.size] = torch.from_numpy(frames.reshape(-1)).cuda()
+    det = m.detect_batch(raw[off:off + frames.size].view(frames.shape))
+else:
+    det = m.detect_batch(frames)
+np.savez(sys.argv[7], stem=m.get_tensor("stem"), inp=m.get_tensor("input"), det=det)
+"""
+
+
+@pytest.mark.parametrize("size,res,dtype,H,W,f32", [("t", 320, "bf16", 270, 480, 0), ("c", 640, "bf16", 640, 640, 0), ("s", 320, "f16", 320, 200, 1),
+                                                    ("t", 640, "bf16", 1080, 1920, 0),      # 3x downscale: 100-row source rectangles staged in LDS
+                                                    ("t", 320, "f16", 199, 301, 0),         # W*3 % 4 != 0: every source row starts at another byte offset
+                                                    ("s", 640, "bf16", 2160, 3840, 0),      # 6x downscale: rectangle too large for LDS, direct loads
+                                                    ("t", 320, "bf16", 90, 160, 0),         # upscale
+                                                    ("c", 640, "f16s", 640, 640, 0),        # split weights: a second MFMA on the low plane
+                                                    ("t", 320, "f16s", 270, 480, 0)])
+def test_fused_letterbox_stem_equals_unfused(tmp_path, size, res, dtype, H, W, f32):
+    """stem_fused_kernel (letterbox + first conv from the frames) against the unfused path (preprocess_kernel -> generic conv)
+    and against the oracle's first layer: same inputs rounded the same way, one MFMA K step instead of two, so at most a
+    last-place difference of the 16-bit result; the "input" tap is rebuilt on demand and must be identical."""
+    import subprocess
+    import sys
+    outs = []
+    for fuse in ("0", "1"):
+        path = str(tmp_path / f"stem{fuse}.npz")
+        env = dict(os.environ, CLEARCAM_FUSE_STEM=fuse, CLEARCAM_TAP_STEM="1",
+                   PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        extra = ["3"] if (H, W) == (199, 301) else []                          # that case also hands over a misaligned device pointer
+        subprocess.run([sys.executable, "-c", _STEM_SCRIPT, size, str(res), dtype, str(H), str(W), str(f32), path] + extra, check=True, env=env)
+        outs.append(np.load(path))
+    a, b = outs
+    assert np.array_equal(a["inp"], b["inp"])                                  # the tap is the same tensor in both modes
+    ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10                         # spacing of the storage type relative to |x| (upper bound)
+    d = np.abs(a["stem"] - b["stem"])
+    assert (d <= ulp * np.maximum(np.abs(a["stem"]), 2.0 ** -6) * 1.01).all(), float(d.max())   # one unit in the last place at most
+    assert (d > 0).mean() < 0.02                                               # and rarely that
+    # first layer of the oracle on the same (rounded) input: SiLU(conv3x3 s2)
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    sd = synthetic_yolov9_state_dict(size, 1234)
+    x = torch.from_numpy(b["inp"]).permute(0, 3, 1, 2)
+    wq = torch.from_numpy(sd["model.list.0.conv.weight"])
+    wq = split_value(wq) if dtype == "f16s" else wq.to(TDT[dtype]).float()
+    ref = F.silu(F.conv2d(x, wq, torch.from_numpy(sd["model.list.0.conv.bias"]), stride=2, padding=1)).permute(0, 2, 3, 1).numpy()
+    assert np.abs(b["stem"] - ref).max() <= 2 * ulp * max(1.0, float(np.abs(ref).max()))
+    n0, n1, nm, _, _ = yo.match_detections(a["det"][0], b["det"][0], 0.5)
+    assert nm >= 0.7 * max(n0, n1, 1) - 1                                      # end to end the two modes stay the same detector
+
+
+_CSP_SCRIPT = r"""
+import sys, numpy as np
+from clearcam_amd.weights import conditioned_yolov9_state_dict, synthetic_yolov9_state_dict
+from clearcam_amd.yolov9 import YOLOv9
+size, res, dtype, H, W, B, out = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+frames = np.random.default_rng(5).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+sd = conditioned_yolov9_state_dict(size, 1234) if size == "c" else synthetic_yolov9_state_dict(size, 1234)
+m = YOLOv9(size, res, state_dict=sd, dtype=dtype, device=0)
+d = {"det": m.detect_batch(frames)}
+for k in range(16):
+    try: d[f"csp{k}_u"] = m.get_tensor(f"csp{k}_u")
+    except Exception: pass
+for n in ("p3", "p4", "p5"): d[n] = m.get_tensor(n)
+d["launches"] = np.array(m.profile(iters=1)["conv_launches"])
+np.savez(out, **d)
+"""
+
+
+@pytest.mark.parametrize("size,res,dtype,H,W,B,level,fused", [
+    ("c", 640, "bf16", 640, 640, 3, "1", 2),      # the bench plan's shapes: hidden width 32 at 160x160 (weights resident, persistent blocks)
+    ("c", 640, "f16", 640, 640, 1, "2", 6),       # + hidden width 64 at 80x80 (weights streamed); a single frame: fewer tiles than CUs
+    ("c", 608, "bf16", 608, 608, 2, "2", 6),      # 152 x 152 and 76 x 76 maps: ragged 8 x 16 tiles on both axes
+    ("c", 640, "bf16", 270, 480, 2, "2", 6),      # letterboxed 384 x 640: non-square maps
+    ("m", 320, "f16", 320, 320, 2, "1", 2),       # YOLOv9-m: one bottleneck per RepNCSP, hidden width 32 at 80x80
+])
+def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fused):
+    """csp_fused_kernel (cv1|cv2, RepConvN 3x3, 3x3 + shortcut, cv3 of a RepNCSP in one launch, intermediates in LDS) against the
+    four launches it replaces: every intermediate is rounded where the layer-at-a-time path stores it and every accumulation runs
+    in the same K order, so block outputs, P3-P5 and the detections are IDENTICAL, bit for bit."""
+    import subprocess
+    import sys
+    outs = []
+    for lv in ("0", level):
+        path = str(tmp_path / f"csp{lv}.npz")
+        env = dict(os.environ, CLEARCAM_FUSE_CSP=lv, CLEARCAM_TAP_CSP="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", _CSP_SCRIPT, size, str(res), dtype, str(H), str(W), str(B), path], check=True, env=env)
+        outs.append(np.load(path))
+    a, b = outs
+    assert int(a["launches"]) - int(b["launches"]) == 3 * fused                # four launches became one, `fused` times
+    names = [n for n in a.files if n.startswith("csp")]
+    assert len(names) >= fused
+    for n in names + ["p3", "p4", "p5", "det"]:
+        assert np.array_equal(a[n], b[n]), n
+    assert np.abs(a["p3"]).max() > 0.05 and np.isfinite(a["p3"]).all()
+
+
 @pytest.mark.parametrize("size,res,dtype,shape", [
     ("c", 640, "f16", (3, 640, 640, 3)),          # the bench network: class branch 256 wide; 3 frames: ragged 64-pixel tiles at 20x20
     ("c", 640, "bf16", (2, 270, 480, 3)),         # letterboxed 384 x 640: non-square maps
     ("s", 320, "f16", (5, 320, 320, 3)),          # class branch 128 wide
     ("e", 640, "bf16", (1, 640, 640, 3)),         # the 43-block graph's head (model.list.42)
+    ("c", 640, "f16s", (3, 640, 640, 3)),         # split weights: rows [hi | lo] in LDS, the pixel fragments walked twice
+    ("s", 320, "f16s", (2, 200, 320, 3)),         # ... class branch 128 wide, non-square maps
 ])
 def test_fused_ddetect_tail_equals_unfused(size, res, dtype, shape):
     """head_tail_kernel (DDetect's last 1x1 convs of both branches + DFL + dist2bbox + sigmoid + class max in one launch, the 144
