@@ -18,9 +18,12 @@
 extern "C" {
 #endif
 
-#define CC_DTYPE_F32 0   /* parity mode: f32 storage, exact-f32 MFMA                  */
-#define CC_DTYPE_F16 1   /* speed mode:  f16 storage, f32 accumulate                  */
-#define CC_DTYPE_BF16 2  /* speed mode:  bf16 storage, f32 accumulate (bench default) */
+#define CC_DTYPE_F32 0   /* parity mode: f32 storage, exact-f32 MFMA (157 TFLOP/s class)                                             */
+#define CC_DTYPE_F16 1   /* speed mode:  f16 storage (activations AND weights rounded to 11 bits), f32 accumulate                    */
+#define CC_DTYPE_BF16 2  /* speed mode:  bf16 storage (8 bits), f32 accumulate                                                       */
+#define CC_DTYPE_F16S 3  /* tolerance mode at MFMA rate (bench default; detector only): f16 activations, every conv weight carried as */
+                         /* TWO f16 planes W = W_hi + W_lo (~22 bits) multiplied into the same f32 accumulator - detections stay      */
+                         /* within the reference tolerance for any float32 checkpoint at twice the MFMA issue of CC_DTYPE_F16        */
 
 #define CC_MAX_DET 300   /* rows per frame of the detector output (detection/yolov9.py:439) */
 
@@ -94,6 +97,11 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
 /* Diagnostic (kernel tuning, tools/dev/phase_ab.py): average device milliseconds of one launch of the conv above on random
  * 16-bit data resident in HBM, weights packed once, `iters` launches between two events.  Not part of the drop-in surface. */
 int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int variant, int iters, float* ms);
+/* Host-only helper (no GPU needed; tests / tooling): the error-feedback rounding cc_yolo_finalize applies to a conv's OIHW float32
+ * weights for the plain 16-bit storage types (dtype 1 / 2) - along each of the `cout` output channels (`per_channel` = Cin*kh*kw
+ * weights each) the rounding residual of a weight is added to the next one before it is rounded.  out[i] = the value the storage
+ * type holds, as float32. */
+int cc_round_weights_feedback(int dtype, const float* w, int64_t cout, int64_t per_channel, float* out);
 /* Diagnostic (kernel tuning): set a process-wide tuning switch at run time so that one process can A/B kernel variants.
  * key "phase_flags": the CLEARCAM_PHASE_FLAGS bit set of the eight-wave kernel (-1 = back to the environment / default).
  * Plans already built keep the launches they were built with.  Not part of the drop-in surface. */

@@ -6,7 +6,9 @@
 add) runs in f32 and the result is rounded ONCE when it is written (clearcam_amd/csrc/conv_mfma.hip
 ``conv_epilogue``).  This class applies exactly those roundings to the oracle:
 
-  * every conv weight            -> storage type (bias stays f32)
+  * every conv weight            -> storage type (bias stays f32); ``feedback=True`` (the library's default, yolo.hip
+                                    ``round_with_feedback``) rounds along each output channel with error feedback: the residual
+                                    of one weight is added to the next before it is rounded
   * the network input  x/255     -> storage type (detect.hip ``stem_fused_kernel`` / ``preprocess_kernel``)
   * every ``Conv`` output        -> storage type after SiLU; a RepNBottleneck's ``x + cv2(cv1(x))``
                                     (detection/yolov9.py:89) is rounded once after the add
@@ -34,12 +36,24 @@ _TORCH_T = {"f16": torch.float16, "bf16": torch.bfloat16}
 
 
 class LowPrecOracle(YOLOv9Oracle):
-    def __init__(self, size: str, res: int, state_dict: Dict[str, np.ndarray], dtype: str):
+    def __init__(self, size: str, res: int, state_dict: Dict[str, np.ndarray], dtype: str, feedback: bool = False):
         super().__init__(size, res, state_dict)
         self.t = _TORCH_T[dtype]
         for k in list(self.sd):
             if k.endswith(".weight") and self.sd[k].ndim == 4 and "dfl" not in k:
-                self.sd[k] = self.q(self.sd[k])
+                self.sd[k] = self.q_feedback(self.sd[k]) if feedback else self.q(self.sd[k])
+
+    def q_feedback(self, w: torch.Tensor) -> torch.Tensor:
+        """clearcam_amd/csrc/yolo.hip ``round_with_feedback``: float32 arithmetic, OIHW order within an output channel."""
+        co = w.shape[0]
+        flat = w.reshape(co, -1).to(torch.float32)
+        q = torch.empty_like(flat)
+        e = torch.zeros(co, dtype=torch.float32)
+        for k in range(flat.shape[1]):
+            t = flat[:, k] + e
+            q[:, k] = self.q(t)
+            e = t - q[:, k]
+        return q.reshape(w.shape)
 
     def q(self, x: torch.Tensor) -> torch.Tensor:
         return x.to(self.t).to(torch.float32)

@@ -80,3 +80,35 @@ def test_synthetic_weights_are_deterministic(sd_t):
     assert not np.array_equal(sd_t["model.list.0.conv.weight"], other["model.list.0.conv.weight"])
     w = sd_t["model.list.4.cv4.conv.weight"]
     assert abs(float(w.mean(axis=(1, 2, 3)).max())) < 1e-6      # zero-sum filters
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_error_feedback_weight_rounding_host(lib_path, dtype):
+    """cc_round_weights_feedback (the rounding cc_yolo_finalize applies to conv weights in the plain 16-bit modes; host code, no GPU):
+    bit-identical to the emulation in oracle/lowprec_oracle.py, every value representable in the storage type, every RUNNING sum of an
+    output channel's weights within half a unit in the last place of the float32 running sum (round-to-nearest lets it random-walk),
+    and values the type already holds exactly are left alone."""
+    import torch
+    from oracle.lowprec_oracle import LowPrecOracle
+    L = _lib.lib()
+    t = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(48, 32, 3, 3, generator=g) * 0.05
+    out = np.empty(w.numel(), np.float32)
+    wn = np.ascontiguousarray(w.numpy())
+    _lib.check(L.cc_round_weights_feedback({"f16": 1, "bf16": 2}[dtype], _lib.ptr(wn), 48, 32 * 9, _lib.ptr(out)))
+    got = torch.from_numpy(out).reshape(w.shape)
+    emu = LowPrecOracle.__new__(LowPrecOracle)
+    emu.t = t
+    assert torch.equal(got, emu.q_feedback(w))                                  # library == emulation, bit for bit
+    assert torch.equal(got, got.to(t).float())                                  # representable
+    run_w = w.reshape(48, -1).double().cumsum(1)
+    run_fb = got.reshape(48, -1).double().cumsum(1)
+    run_nr = w.to(t).float().reshape(48, -1).double().cumsum(1)
+    ulp = 2.0 ** (np.floor(np.log2(float(w.abs().max()))) - (10 if dtype == "f16" else 7))
+    assert float((run_fb - run_w).abs().max()) <= 0.51 * ulp                    # the residual carried along never exceeds half an ulp
+    assert float((run_nr - run_w).abs().max()) > 2 * float((run_fb - run_w).abs().max())   # nearest rounding drifts
+    exact = w.to(t).float()
+    _lib.check(L.cc_round_weights_feedback({"f16": 1, "bf16": 2}[dtype], _lib.ptr(np.ascontiguousarray(exact.numpy())), 48, 32 * 9, _lib.ptr(out)))
+    assert np.array_equal(out.reshape(w.shape), exact.numpy())
+    assert L.cc_round_weights_feedback(0, _lib.ptr(wn), 48, 288, _lib.ptr(out)) != 0       # f32 storage has nothing to round

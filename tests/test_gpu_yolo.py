@@ -343,7 +343,7 @@ def conditioned_case(frames, chunk=8, exact=True, emulate=()):
         from oracle.lowprec_oracle import LowPrecOracle
         emu = {}
         for dt in emulate:
-            lo = LowPrecOracle("c", res, sd, dt)
+            lo = LowPrecOracle("c", res, sd, dt, feedback=True)           # the library rounds weights with error feedback (yolo.hip round_with_feedback)
             d2, c2 = [], []
             with torch.no_grad():
                 for i in range(0, len(frames), chunk):

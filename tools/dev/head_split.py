@@ -4,6 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from clearcam_amd import _lib
 L = _lib.lib()
+DT = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 for name, B, H, W, Cin, Cout, k, stride, v in [("3x3 256->320 @80", 64, 80, 80, 256, 320, 3, 1, 0), ("3x3 256->256 @80", 64, 80, 80, 256, 256, 3, 1, 0),
                                                ("3x3 256->64 @80 auto", 64, 80, 80, 256, 64, 3, 1, 0), ("3x3 256->64 @80 generic", 64, 80, 80, 256, 64, 3, 1, 2),
                                                ("3x3 256->64 @80 halo", 64, 80, 80, 256, 64, 3, 1, 3), ("3x3 256->64 @80 few-tile", 64, 80, 80, 256, 64, 3, 1, 9),
@@ -14,7 +15,7 @@ for name, B, H, W, Cin, Cout, k, stride, v in [("3x3 256->320 @80", 64, 80, 80, 
                                                ("3x3 512->64 @20 auto", 64, 20, 20, 512, 64, 3, 1, 0), ("3x3 512->64 @20 generic", 64, 20, 20, 512, 64, 3, 1, 2)]:
     try:
         for r in range(2):
-            ms = C.c_float(); _lib.check(L.cc_conv_bench(2, B, H, W, Cin, Cout, k, stride, 1, v, 20, C.byref(ms)))
+            ms = C.c_float(); _lib.check(L.cc_conv_bench(DT, B, H, W, Cin, Cout, k, stride, 1, v, 20, C.byref(ms)))
         print(name, round(ms.value * 1e3, 1), "us", flush=True)
     except Exception as e:
         print(name, "error", e, flush=True)

@@ -8,7 +8,7 @@ from clearcam_amd import _lib
 L = _lib.lib()
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["kind"] == "conv"]
 B = int(sys.argv[2])
-DT = {"f16": 1, "bf16": 2}[sys.argv[3] if len(sys.argv) > 3 else "f16"]
+DT = {"f16": 1, "bf16": 2, "f16s": 3}[sys.argv[3] if len(sys.argv) > 3 else "f16"]
 shapes = {}
 for r in rows:
     M, Cin, Cout, ks, st = int(float(r["M"])), int(r["Cin"]), int(r["Cout"]), int(r["ks"]), int(r["stride"])
