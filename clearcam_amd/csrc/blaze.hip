@@ -246,7 +246,7 @@ int cc_blaze_create(cc_blaze** h, int dtype, int device) {
   CC_HIP(hipSetDevice(device));
   std::unique_ptr<cc_blaze> b(new cc_blaze());
   b->dtype = dtype; b->device = device;
-  CC_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  b->stream = pool_stream_get(device);
   *h = b.release();
   CC_API_END
 }
@@ -320,7 +320,7 @@ void cc_blaze_destroy(cc_blaze* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   h->plans.clear();
   for (void* p : h->wallocs) hipFree(p);
-  if (h->stream) hipStreamDestroy(h->stream);
+  pool_stream_put(h->device, h->stream);                  // parked, never destroyed (kernels.h)
   delete h;
 }
 

@@ -232,7 +232,7 @@ int cc_clip_create(cc_clip** h, const cc_clip_config* cfg, int dtype, int device
   CC_HIP(hipSetDevice(device));
   std::unique_ptr<cc_clip> c(new cc_clip());
   c->cfg = *cfg; c->dtype = dtype; c->device = device;
-  CC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->stream = pool_stream_get(device);
   CC_HIP(hipEventCreate(&c->ev0)); CC_HIP(hipEventCreate(&c->ev1));
   *h = c.release();
   CC_API_END
@@ -325,8 +325,9 @@ int cc_clip_set_in_flight(cc_clip* h, int n) {
   CC_HIP(hipSetDevice(h->device));
   CC_HIP(hipStreamSynchronize(h->stream));
   for (hipStream_t t : h->slot_stream) CC_HIP(hipStreamSynchronize(t));
-  while ((int)h->slot_stream.size() > n - 1) { hipStreamDestroy(h->slot_stream.back()); h->slot_stream.pop_back(); }
-  grow_slot_streams(h->stream, h->slot_stream, n - 1);
+  if (n == (int)h->slot_stream.size() + 1) return 0;   // same depth: slots and tickets stay valid
+  while ((int)h->slot_stream.size() > n - 1) { pool_stream_put(h->device, h->slot_stream.back()); h->slot_stream.pop_back(); }
+  grow_slot_streams(h->device, h->stream, h->slot_stream, n - 1);
   while ((int)h->slot_done.size() > n) { hipEventDestroy(h->slot_done.back()); h->slot_done.pop_back(); }
   while ((int)h->slot_done.size() < n) { hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->slot_done.push_back(e); }
   h->submitted = 0;
@@ -409,12 +410,12 @@ void cc_clip_destroy(cc_clip* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (hipStream_t t : h->slot_stream) hipStreamSynchronize(t);
   h->img_plans.clear(); h->txt_plans.clear();
-  for (hipStream_t t : h->slot_stream) hipStreamDestroy(t);
+  for (hipStream_t t : h->slot_stream) pool_stream_put(h->device, t);       // parked, never destroyed (kernels.h)
   for (hipEvent_t e : h->slot_done) hipEventDestroy(e);
   for (void* p : h->wallocs) hipFree(p);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
-  if (h->stream) hipStreamDestroy(h->stream);
+  pool_stream_put(h->device, h->stream);
   delete h;
 }
 

@@ -217,7 +217,7 @@ int cc_face_create(cc_face** h, int dtype, int device) {
   CC_HIP(hipSetDevice(device));
   std::unique_ptr<cc_face> f(new cc_face());
   f->dtype = dtype; f->device = device;
-  CC_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  f->stream = pool_stream_get(device);
   *h = f.release();
   CC_API_END
 }
@@ -309,7 +309,7 @@ void cc_face_destroy(cc_face* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   h->plans.clear();
   for (void* p : h->wallocs) hipFree(p);
-  if (h->stream) hipStreamDestroy(h->stream);
+  pool_stream_put(h->device, h->stream);                  // parked, never destroyed (kernels.h)
   delete h;
 }
 

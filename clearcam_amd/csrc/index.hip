@@ -390,7 +390,7 @@ int cc_index_create_ex(cc_index** h, int dim, int64_t capacity, int device, int 
   x->dim = dim; x->capacity = capacity; x->device = device; x->storage = storage;
   CC_HIP(hipMalloc((void**)&x->emb, (size_t)capacity * x->row_bytes() + 256));
   CC_HIP(hipMalloc((void**)&x->grp, (size_t)capacity * 4 + 256));
-  CC_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+  x->stream = pool_stream_get(device);
   *h = x.release();
   CC_API_END
 }
@@ -540,7 +540,7 @@ void cc_index_destroy(cc_index* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->emb, (void*)h->grp, (void*)h->allowed, (void*)h->q16, (void*)h->q_dev, (void*)h->scores, (void*)h->cand, (void*)h->idx_dev, (void*)h->sc_dev}) if (p) hipFree(p);
   if (h->pin) hipHostFree(h->pin);
-  if (h->stream) hipStreamDestroy(h->stream);
+  pool_stream_put(h->device, h->stream);                  // parked, never destroyed (kernels.h)
   delete h;
 }
 

@@ -114,9 +114,14 @@ struct HeadTailP {
 };
 bool head_tail_supported(int dt, int ch, int split = 0);
 void launch_head_tail(int dt, const HeadTailP& p, hipStream_t stream);
+// Streams of handles come from a process-wide pool per device and go back to it when a handle dies - they are NEVER destroyed.
+// Destroying streams makes the runtime re-deal its few hardware queues, and a handle created afterwards has been seen replaying
+// its captured graph 3x slower for its whole life ("Uploads"); parked streams keep the queue assignment stable.
+hipStream_t pool_stream_get(int device);                 // a non-blocking stream of `device` (the device must be current)
+void pool_stream_put(int device, hipStream_t s);         // idle it and park it for the next handle
 // batches in flight (yolo.hip): streams for the extra slots of a handle, probed until kernels on them overlap with `base` and each other
 bool streams_overlap(hipStream_t a, hipStream_t b);
-void grow_slot_streams(hipStream_t base, std::vector<hipStream_t>& slots, int n_extra);
+void grow_slot_streams(int device, hipStream_t base, std::vector<hipStream_t>& slots, int n_extra);
 
 struct NmsP {                 // top-300 + mask NMS + scale_boxes: detection/yolov9.py:406-458
   const float* det; int B, A;

@@ -12,8 +12,10 @@
 //     same feature map (:205-206) are fused into one GEMM each (weights concatenated along Cout).
 //   * RepNBottleneck's residual (:89) is the conv epilogue, written in place.
 //   * grouped head convs (:172-181, K=144/16 per group) are densified to block-diagonal weights.
+#include <deque>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <cmath>
@@ -827,7 +829,7 @@ static void run_ops_lanes(cc_yolo* Y, Plan* P, hipStream_t s) {
   int nl = 1;
   for (const Op& op : P->ops) nl = std::max(nl, op.lane + 1);
   if (nl == 1) { run_ops(Y, P, s); return; }
-  while ((int)Y->side.size() < nl - 1) { hipStream_t t; CC_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); Y->side.push_back(t); }
+  while ((int)Y->side.size() < nl - 1) Y->side.push_back(pool_stream_get(Y->device));
   auto stream_of = [&](int lane) { return lane == 0 ? s : Y->side[lane - 1]; };
   std::vector<hipEvent_t>& ev = P->lane_ev;             // owned by the plan: they outlive the capture
   ev.assign(nops + 1, nullptr);
@@ -947,20 +949,39 @@ bool streams_overlap(hipStream_t a, hipStream_t b) {
 // replaced until it overlaps with all of them; rejected streams stay alive until the end so that the runtime moves on to another
 // queue.  (Stream priority classes have queue pools of their own and would separate three slots by construction, but strict
 // priority only fills gaps: 10.7 ms per B = 64 detect step against 10.1 with three equal slots.)
-void grow_slot_streams(hipStream_t base, std::vector<hipStream_t>& slots, int n_extra) {
+static std::mutex g_pool_mu;
+static std::map<int, std::deque<hipStream_t>> g_pool;
+hipStream_t pool_stream_get(int device) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto& q = g_pool[device];
+    if (!q.empty()) { hipStream_t s = q.front(); q.pop_front(); return s; }
+  }
+  hipStream_t s = nullptr;
+  CC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+void pool_stream_put(int device, hipStream_t s) {
+  if (!s) return;
+  hipStreamSynchronize(s);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool[device].push_back(s);
+}
+
+void grow_slot_streams(int device, hipStream_t base, std::vector<hipStream_t>& slots, int n_extra) {
   std::vector<hipStream_t> rejected;
   while ((int)slots.size() < n_extra) {
     hipStream_t t = nullptr;
     for (int attempt = 0; attempt < 12; ++attempt) {
-      CC_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
+      t = pool_stream_get(device);
       bool ok = streams_overlap(base, t);
       for (size_t j = 0; ok && j < slots.size(); ++j) ok = streams_overlap(slots[j], t);
       if (ok || attempt == 11) break;
-      rejected.push_back(t); t = nullptr;
+      rejected.push_back(t); t = nullptr;               // held until the end, so that the pool / the runtime moves on to another queue
     }
     slots.push_back(t);
   }
-  for (hipStream_t t : rejected) hipStreamDestroy(t);
+  for (hipStream_t t : rejected) pool_stream_put(device, t);
 }
 
 }  // namespace cc
@@ -998,7 +1019,7 @@ int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device
   CC_HIP(hipSetDevice(device));
   std::unique_ptr<cc_yolo> y(new cc_yolo());
   y->arch = a; y->res = res; y->dtype = storage_dtype(dtype); y->wsplit = dtype == F16S; y->device = device;
-  CC_HIP(hipStreamCreateWithFlags(&y->stream, hipStreamNonBlocking));
+  y->stream = pool_stream_get(device);
   CC_HIP(hipEventCreate(&y->ev0)); CC_HIP(hipEventCreate(&y->ev1));
   *h = y.release();
   CC_API_END
@@ -1099,11 +1120,12 @@ int cc_yolo_set_in_flight(cc_yolo* h, int n) {
   CC_API_BEGIN
   CC_CHECK(h && n >= 1 && n <= 8, "in-flight depth must be 1..8");
   CC_HIP(hipSetDevice(h->device));
+  if (n == (int)h->slot_stream.size() + 1 && !h->slot_done.empty()) return 0;   // same depth: plans, slots and outstanding tickets stay valid
   sync_all(h);
   h->plans.clear();                                     // plans are built for one depth (lanes on or off) and belong to a slot
   h->last = nullptr;
-  while ((int)h->slot_stream.size() > n - 1) { hipStreamDestroy(h->slot_stream.back()); h->slot_stream.pop_back(); }
-  grow_slot_streams(h->stream, h->slot_stream, n - 1);      // probed: kernels on any two of them really run side by side
+  while ((int)h->slot_stream.size() > n - 1) { pool_stream_put(h->device, h->slot_stream.back()); h->slot_stream.pop_back(); }
+  grow_slot_streams(h->device, h->stream, h->slot_stream, n - 1);      // probed: kernels on any two of them really run side by side
   while ((int)h->slot_done.size() > n) { hipEventDestroy(h->slot_done.back()); h->slot_done.pop_back(); }
   while ((int)h->slot_done.size() < n) { hipEvent_t e; CC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->slot_done.push_back(e); }
   h->submitted = 0;
@@ -1313,10 +1335,10 @@ void cc_yolo_destroy(cc_yolo* h) {
   if (h->dfl_w) hipFree(h->dfl_w);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
-  for (hipStream_t t : h->side) hipStreamDestroy(t);
-  for (hipStream_t t : h->slot_stream) hipStreamDestroy(t);
+  for (hipStream_t t : h->side) pool_stream_put(h->device, t);              // parked, never destroyed (kernels.h)
+  for (hipStream_t t : h->slot_stream) pool_stream_put(h->device, t);
   for (hipEvent_t e : h->slot_done) hipEventDestroy(e);
-  if (h->stream) hipStreamDestroy(h->stream);
+  pool_stream_put(h->device, h->stream);
   delete h;
 }
 

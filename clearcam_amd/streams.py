@@ -58,7 +58,7 @@ class SyntheticCamera:
 class CameraBank(list):
     """The cameras of one GPU writing into ONE pinned buffer (ring, N, H, W, 3): camera i's decode thread owns row i of every ring
     slot, so the frames of a tick are contiguous and go up as a single copy - 57 GB/s over PCIe gen5 against 44 GB/s for N copies of
-    one 6 MB frame each (MI355X box, profiles/r03s_h2d_rate.txt).  A list of the N SyntheticCamera objects (each still has read())
+    one 6 MB frame each (MI355X box, tools/dev/h2d_rate.py; DESIGN.md section 4, "Uploads").  A list of the N SyntheticCamera objects (each still has read())
     plus read_all()."""
 
     def __init__(self, n: int, height: int = 1080, width: int = 1920, ring: int = 2, seed: int = 100):
@@ -81,12 +81,12 @@ _STREAMS: Dict[tuple, tuple] = {}            # (device, copy streams) -> ([copy 
 
 
 class _Slot:
-    def __init__(self, n, h, w, dev):
+    def __init__(self, n, h, w, dev, n_copy_streams=1):
         import torch
         self.frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
         self.out = torch.empty((n, 300, 6), dtype=torch.float32, device=dev)
         self.host_out = torch.empty((n, 300, 6), dtype=torch.float32).pin_memory()
-        self.ups, self.done = [torch.cuda.Event() for _ in range(8)], torch.cuda.Event()
+        self.ups, self.done = [torch.cuda.Event() for _ in range(max(1, n_copy_streams))], torch.cuda.Event()   # one upload event per copy stream
         self.ticket = None                                   # detector-slot submission (in_flight mode)
         self.t_submit = 0.0
 
@@ -124,10 +124,18 @@ class StreamPipeline:
         if depth is None:
             depth = 4 if in_flight else 2
         self.depth = depth
-        self.slots = [_Slot(n_cams, frame_hw[0], frame_hw[1], self.dev) for _ in range(depth)]
+        self.slots = [_Slot(n_cams, frame_hw[0], frame_hw[1], self.dev, len(self.copy_streams)) for _ in range(depth)]
         self.in_flight = bool(in_flight) and hasattr(model, "submit") and depth > 1
+        # A model may serve one pipeline at a time in detector-slot mode: changing the depth drops the handle's plans and restarts its
+        # ticket counter, which would invalidate the tickets another live pipeline holds (same depth: cc_yolo_set_in_flight is a no-op)
+        users = getattr(model, "_pipelines", None)
+        if users is None:
+            users = model._pipelines = set()
         if self.in_flight:
+            if any(p.in_flight and p.depth != depth for p in users):
+                raise RuntimeError("this model already serves a pipeline with another number of detector slots: close() that pipeline first")
             model.set_in_flight(depth)
+        users.add(self)
         if n_threads is None:
             try:
                 n_threads = len(os.sched_getaffinity(0))
@@ -210,6 +218,14 @@ class StreamPipeline:
     def run(self, cameras: Optional[List[SyntheticCamera]], n_batches: int, warmup: int = 2) -> Dict[str, float]:
         """Steady-state loop over n_batches (+warmup) batches; cameras=None benchmarks with frames resident in HBM."""
         torch = self.torch
+        # A tick's pinned frames are the SOURCE of an asynchronous upload that may still be pending `depth` ticks later (that many
+        # batches are in flight): the decode threads must not come back to a ring slot before then
+        ring = getattr(cameras, "ring", None) if cameras is not None else None
+        if ring is None and cameras is not None and len(cameras):
+            ring = getattr(cameras[0], "ring", None)
+        if ring is not None and ring < self.depth + 1:
+            raise ValueError(f"camera ring of {ring} frames is too short for {self.depth} batches in flight: a frame would be overwritten while "
+                             f"its upload is pending (need ring >= depth + 1 = {self.depth + 1}; make_cameras(n, ring=...))")
         grab = (lambda: None) if cameras is None else cameras.read_all if hasattr(cameras, "read_all") else (lambda: [c.read() for c in cameras])
         if cameras is None:
             for s in self.slots:                                  # something to detect on
@@ -254,10 +270,15 @@ class StreamPipeline:
     def close(self):
         for t in self.trackers:
             t.close()
+        getattr(self.model, "_pipelines", set()).discard(self)
 
 
-def make_cameras(n: int, height: int = 1080, width: int = 1920, ring: int = 2, seed: int = 100, bank: bool = True) -> List[SyntheticCamera]:
-    """N synthetic cameras; bank=True (default): their rings are rows of one pinned buffer (CameraBank: one upload per tick)."""
+def make_cameras(n: int, height: int = 1080, width: int = 1920, ring: Optional[int] = None, seed: int = 100, bank: bool = True) -> List[SyntheticCamera]:
+    """N synthetic cameras; bank=True (default): their rings are rows of one pinned buffer (CameraBank: one upload per tick).
+    ring: frames per camera; default = StreamPipeline's default depth for that camera count + 1 (a frame is the source of an
+    asynchronous upload for up to `depth` ticks)."""
+    if ring is None:
+        ring = 5 if n <= 8 else 3
     if bank:
         return CameraBank(n, height, width, ring, seed)
     base = np.random.default_rng(seed).integers(0, 256, (height, width, 3), dtype=np.uint8)
