@@ -4,7 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the detect hot path (letterbox -> 144 convs -> decode -> top-300 + mask NMS)
-over one batch of 64 synthetic 640x640 BGR uint8 frames that are already resident in HBM.  The K timed steps are
+over one batch of 64 synthetic 640x640 BGR uint8 frames that are already resident in HBM.  The headline storage mode is
+"f16s": f16 activations with every conv weight carried as two f16 planes (W_hi + W_lo, f32 accumulation) - the 16-bit mode
+whose detections stay inside the reference tolerance with UN-ROUNDED float32 weights (measured in this run: `parity`); plain
+f16 / bf16 (weights rounded to 11 / 8 bits) are reported beside it as speed modes, f32 as the exact-arithmetic mode.  The K timed steps are
 submitted round robin to `--in-flight` (default 3) slots of one handle (cc_yolo_submit: own stream, arena and graph
 per slot, so consecutive batches overlap on the GPU; bit-identical rows) and all complete inside the timed region;
 the same K steps as back-to-back cc_yolo_detect calls are reported beside it (`one_batch_in_flight`).  With N>1
@@ -17,8 +20,10 @@ the caller has put in place (tests/test_bench_multi.py mocks them); the default 
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      dominant kernel family (the conv kernels): algorithmic FLOPs per step / their summed duration per
-                step with ONE batch in flight (rocprofv3's kernel durations when the committed trace matches the kernel
-                sources by digest, else live: whole-step hipGraph minus non-conv hipGraph, hipEvents on the launch stream)
+                step with ONE batch in flight, measured LIVE in this run (whole-step hipGraph minus non-conv hipGraph,
+                hipEvents on the launch stream); the committed rocprofv3 trace of the same kernels (digest-, device- and
+                dtype-checked) is the referee beside it (frac_rocprofv3).  Split weights issue two MFMAs per algorithmic
+                multiply-add: `frac` counts the algorithmic FLOPs, `frac_mfma_issued` the matrix-pipe work
   cpu_baseline  the PyTorch-CPU fp32 oracle (restatement of the reference; tinygrad's CPU path cannot
                 run offline) timed on this host's cores on a bounded sample, batch 1 as the reference runs it
 """
@@ -34,7 +39,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16s": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+MFMA_PER_MAC = {"f16s": 2.0}                                    # split weights: two matrix instructions per algorithmic multiply-add
+HBM_PEAK = 8.0e12
 FLOP_PER_FRAME_C640 = 2 * 51.068e9
 
 
@@ -70,7 +77,16 @@ def cpu_baseline(size: str, res: int, seconds: float = 10.0, with_clip: bool = T
     frames = np.random.default_rng(1).integers(0, 256, (8, res, res, 3), dtype=np.uint8)
     n1, t1 = _timed_loop(lambda: o(frames[0]), seconds)
     n8, t8 = _timed_loop(lambda: o.detect_batch(frames), seconds / 2)
+    # the thread count is a choice, so it is measured: the batch-1 detector at 16 / 64 / all usable threads (~2 s each); `value` keeps
+    # the default (CLEARCAM_CPU_THREADS or min(usable, 16)): one batch-1 conv stream does not scale past a few dozen threads
+    sweep = {}
+    for th in sorted({min(avail, t) for t in (16, 64, avail)}):
+        torch.set_num_threads(th)
+        ns, ts = _timed_loop(lambda: o(frames[0]), 2.0)
+        sweep[str(th)] = round(ns / ts, 3)
+    torch.set_num_threads(cores)
     out = {"value": round(n1 / t1, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+           "frames_per_sec_by_threads": sweep,
            "host_cores_usable": avail, "kind": "port",
            "sample": f"{n1} frames of {res}x{res}, batch 1 (reference semantics), PyTorch-CPU fp32 restatement "
                      f"of detection/yolov9.py (tinygrad CPU path not runnable offline)",
@@ -150,8 +166,18 @@ def measured_parity(device_index: int, n_cond: int = 16, n_chaotic: int = 4) -> 
     for label, exact in (("weights_16bit_exact", True), ("weights_unrounded", False)):
         sd = conditioned_yolov9_state_dict("c", 1234, exact=exact)
         ref = oracle(sd, fr)
-        out[label] = {dt: summary(ref, hip(sd, fr, dt)) for dt in ("f16", "bf16")}
+        out[label] = {dt: summary(ref, hip(sd, fr, dt)) for dt in ("f16s", "f16", "bf16")}
         out[label]["frames"] = n_cond
+    # the bar a mode has to hold WITH UN-ROUNDED WEIGHTS (a trained checkpoint is float32: detection/yolov9.py:372-373) to carry the
+    # north star's "within 1e-3": every anchor's box within 1e-3 * max(H, W), scores within 2e-3, >= 98.5 % strict matches clear of the
+    # 0.25 threshold (>= 97.5 % with every row counted)
+    def holds(s):
+        return bool(s["anchor_box_err_px_max"] <= tol and s["anchor_score_err_max"] <= 2e-3 and
+                    s["match_frac_clear_of_threshold"] >= 0.985 and s["match_frac"] >= 0.975)
+    out["holds_tolerance_with_unrounded_weights"] = {dt: holds(out["weights_unrounded"][dt]) for dt in ("f16s", "f16", "bf16")}
+    out["holds_tolerance_note"] = ("per-anchor box error <= 0.64 px for every anchor, scores within 2e-3, >= 98.5 % strict matches clear of the threshold, against the "
+                                   "f32 oracle on the conditioned checkpoint with its float32 weights NOT pre-rounded; f16 / bf16 round their weights with error feedback "
+                                   "(yolo.hip round_with_feedback), f16s carries them as two f16 planes")
     return out
 
 
@@ -342,9 +368,9 @@ def stream_side_metrics(device_index: int, size: str, res: int, dtype: str) -> d
     out = {}
     sd = synthetic_yolov9_state_dict(size, 1234)
     banks = {64: make_cameras(64), 8: make_cameras(8)}          # one pinned bank per camera count: a tick goes up as ONE copy
-    # (the 8-camera leg goes last: it uses detector slots, and a pipeline created right after one with slots has been torn down has
-    # replayed its graph slowly on this runtime - DESIGN.md section 4, "Uploads")
-    for key, n, shift in (("cams64", 64, -20.0), ("cams64_crowded", 64, 0.0), ("cams8", 8, -20.0)):
+    # (the 8-camera leg - detector slots - runs FIRST and the plain pipelines after it: the order that replayed graphs slowly in round 3;
+    # tests/test_gpu_streams.py::test_pipeline_after_slotted_pipeline_replays_at_full_speed holds it)
+    for key, n, shift in (("cams8", 8, -20.0), ("cams64", 64, -20.0), ("cams64_crowded", 64, 0.0)):
         m = YOLOv9(size, res, state_dict=shift_class_bias(sd, shift), dtype=dtype, device=device_index)
         pipe = StreamPipeline(m, n)
         cams = banks[n]
@@ -367,7 +393,7 @@ def kernel_source_digest() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(default_cfg: bool):
+def measured_traffic(default_cfg: bool, dtype: str = "f16s"):
     """HBM bytes per step of the conv kernels from this round's rocprofv3 PMC passes (profiles/pmc_traffic.json, written
     by tools/pmc_traffic.py on the GPU box).  A file taken from other kernels than the ones in the tree is NOT quoted."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
@@ -376,6 +402,8 @@ def measured_traffic(default_cfg: bool):
     if not os.path.exists(path):
         return None, "profiles/pmc_traffic.json missing: run tools/pmc_traffic.py on the GPU box"
     rec = json.load(open(path))
+    if rec.get("dtype", "f16") != dtype:
+        return None, f"profiles/pmc_traffic.json was recorded for dtype {rec.get('dtype', 'f16')}"
     if rec.get("kernel_source_digest") != kernel_source_digest():
         print(f"bench: profiles/pmc_traffic.json was measured on other kernels ({rec.get('kernel_source_digest')} != "
               f"{kernel_source_digest()}); roofline.traffic left null — re-run tools/pmc_traffic.py", file=sys.stderr)
@@ -383,14 +411,16 @@ def measured_traffic(default_cfg: bool):
     return float(rec["conv_bytes_per_step"]), rec.get("note", "")
 
 
-def traced_kernel_ms(default_cfg: bool):
+def traced_kernel_ms(default_cfg: bool, dtype: str, device_name: str):
     """Conv-family kernel time per step from this round's rocprofv3 --kernel-trace --stats run (profiles/kernel_trace.json, written
-    by tools/measure_round.sh on the GPU box), quoted only for the kernels it was taken from."""
+    by tools/measure_round.sh on the GPU box): the REFEREE beside the live measurement, quoted only for the kernel sources (digest),
+    storage mode and device model it was taken on."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "kernel_trace.json")
     if not default_cfg or not os.path.exists(path):
         return None
     rec = json.load(open(path))
-    return rec if rec.get("kernel_source_digest") == kernel_source_digest() else None
+    ok = rec.get("kernel_source_digest") == kernel_source_digest() and rec.get("dtype") == dtype and rec.get("device_name") in (None, device_name)
+    return rec if ok else None
 
 
 def main() -> None:
@@ -403,9 +433,9 @@ def main() -> None:
     ap.add_argument("--res", type=int, default=640)
     ap.add_argument("--height", type=int, default=0, help="source frame height (default: res)")
     ap.add_argument("--width", type=int, default=0, help="source frame width (default: res)")
-    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f32"],
-                    help="storage / MFMA operand type.  f16 is the default: it is the 16-bit mode that meets the f32 gate's own parity yardstick "
-                         "(bf16's 8 significant bits cannot; DESIGN.md section 5), at the same MFMA rate")
+    ap.add_argument("--dtype", default="f16s", choices=["f16s", "bf16", "f16", "f32"],
+                    help="storage mode.  f16s (default): f16 activations, every conv weight as two f16 planes - the 16-bit mode that holds the parity "
+                         "yardstick with un-rounded float32 weights (DESIGN.md section 5).  f16 / bf16: speed modes (weights rounded to 11 / 8 bits); f32: exact")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight (cc_yolo_submit on that many slots of one handle: the last layers of one batch overlap the first "
                          "layers of the next); 1 = back-to-back cc_yolo_detect calls.  Both are measured; `value` is this mode")
@@ -506,6 +536,23 @@ def main() -> None:
         mine[rank] = (time.perf_counter() - t0) / args.steps * 1e3
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(v), 3) for v in mine.tolist()]
+    # what the batches in flight cost: submit-to-result latency of one batch in the steady state (host clock, result waited for on the host)
+    latency = None
+    if world == 1 and depth > 1 and on_gpu:
+        try:
+            run = runner(model_p, depth)
+            tk, t_sub, lat = [], [], []
+            for k in range(4 * depth + 12):
+                if len(tk) == depth:
+                    model_p.wait(tk.pop(0), host=True); lat.append(time.perf_counter() - t_sub.pop(0))
+                t_sub.append(time.perf_counter()); tk.append(run(k))
+            for t in tk:
+                model_p.wait(t, host=True)
+            lat = sorted(lat[depth:])
+            latency = {"p50": round(lat[len(lat) // 2] * 1e3, 3), "max": round(lat[-1] * 1e3, 3), "batches_in_flight": depth,
+                       "one_in_flight": round(elapsed_one / args.steps * 1e3, 3)}
+        except Exception as exc:                 # noqa: BLE001  a side metric
+            latency = {"error": f"{type(exc).__name__}: {exc}"}
     if model_p is not model:
         model_p.close()
     n_det = int((out[..., 4] > 0).sum().item())
@@ -528,7 +575,7 @@ def main() -> None:
     precisions = None
     if not args.no_precisions and world == 1:
         precisions = {args.dtype: round(B * args.steps / elapsed, 1)}
-        for dt_name, steps in (("bf16", args.steps), ("f16", args.steps), ("f32", max(3, args.steps // 4))):
+        for dt_name, steps in (("f16s", args.steps), ("f16", args.steps), ("bf16", args.steps), ("f32", max(3, args.steps // 4))):
             if dt_name in precisions:
                 continue
             try:
@@ -594,9 +641,16 @@ def main() -> None:
         os.environ.pop("CLEARCAM_PROFILE_CSV", None)
         heaviest = None
         stem_flops = 0.0
+        per_launch_roof = None
         try:
             table = list(csv.DictReader(open(tmp_csv)))
             stem_flops = sum(2e9 * float(r["alg_gmac"]) for r in table if r["kind"] == "stem_fused")
+            # per-launch roof: every launch of the plan against max(its algorithmic FLOPs / MFMA peak, its minimum bytes / 8 TB/s)
+            ideal = sum(max(2e9 * float(r["alg_gmac"]) / (PEAK_TFLOPS[args.dtype] * 1e12), float(r["gbytes_min"]) * 1e9 / HBM_PEAK) for r in table) * 1e3
+            spent = sum(float(r["ms"]) for r in table)
+            per_launch_roof = {"ideal_ms": round(ideal, 3), "measured_ms": round(spent, 3), "frac": round(ideal / spent, 4),
+                               "how": "sum over the plan's launches of max(algorithmic FLOPs / dense MFMA peak, minimum bytes / 8 TB/s) over the sum of their "
+                                      "hipEvent-timed durations (eager replay, ~0.3 ms of event overhead per step inside the denominator)"}
             rows = [r for r in table if r["kind"] == "conv"]
             top = max(rows, key=lambda r: float(r["ms"]))
             heaviest = {"layer": f"{top['ks']}x{top['ks']} s{top['stride']} {top['Cin']}->{top['Cout']}, {int(float(top['M']))} output pixels",
@@ -622,21 +676,20 @@ def main() -> None:
             g_all, g_other, g_conv = model.profile_graph(2, 10), model.profile_graph(1, 10), model.profile_graph(0, 10)
         except Exception:                         # noqa: BLE001  older library / mocked model
             pass
-        default_cfg = (args.size, args.res, B, args.dtype, fh, fw) == ("c", 640, 64, "f16", 640, 640)
-        traffic, traffic_note = measured_traffic(default_cfg)
-        traced = traced_kernel_ms(default_cfg)
+        default_cfg = (args.size, args.res, B, fh, fw) == ("c", 640, 64, 640, 640)
+        device_name = torch.cuda.get_device_name(local) if on_gpu else "cpu"
+        traffic, traffic_note = measured_traffic(default_cfg, args.dtype)
+        traced = traced_kernel_ms(default_cfg, args.dtype, device_name)
         peak = PEAK_TFLOPS[args.dtype]
-        # `achieved` / `frac`: the conv kernels' time per step from rocprofv3's own kernel durations when the committed trace was taken
-        # from exactly these kernels (profiles/kernel_trace.json, digest-checked); otherwise the live in-plan measurement (graph
-        # subtraction), otherwise the eager per-launch event sum.  All three are always reported side by side; `frac_source` says
-        # which one `frac` is.
-        live_s = ((g_all - g_other) if g_all and g_other else prof["conv_ms"]) * 1e-3
-        if traced:
-            conv_s, frac_source = traced["conv_ms_per_step"] * 1e-3, "rocprofv3 kernel durations (profiles/kernel_trace.json, same kernel sources by digest)"
-        elif g_all and g_other:
-            conv_s, frac_source = live_s, "live: whole-step hipGraph minus non-conv-launch hipGraph (no rocprofv3 trace of these kernel sources committed)"
+        # `achieved` / `frac` are measured IN THIS RUN: the conv launches' time inside the plan = whole step replayed as a hipGraph minus
+        # every non-conv launch replayed as a hipGraph (one hipEvent pair around ten replays each, on the launch stream); the eager
+        # per-launch event sum is the fallback.  The committed rocprofv3 trace of the same kernel sources / storage mode / device model
+        # is the referee, reported beside it (frac_rocprofv3) and never substituted for the live number.
+        if g_all and g_other:
+            conv_s, frac_source = (g_all - g_other) * 1e-3, "live in this run: whole-step hipGraph minus non-conv-launch hipGraph, hipEvents on the launch stream"
         else:
-            conv_s, frac_source = live_s, "live: sum of per-launch hipEvent pairs, eager replay (graph profile unavailable)"
+            conv_s, frac_source = prof["conv_ms"] * 1e-3, "live in this run: sum of per-launch hipEvent pairs, eager replay (graph profile unavailable)"
+        live_s = conv_s
         achieved = alg_flops / conv_s / 1e12
         line = {
             "metric": f"yolov9{args.size}_{args.res}x{args.res}_frames_per_sec" if (fh, fw) == (args.res, args.res)
@@ -660,7 +713,11 @@ def main() -> None:
             "ranks_seen": ranks_seen, "ms_per_step_by_rank": per_rank_ms,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "frac_source": frac_source,
-                         "frac_live_graph_subtraction": round(alg_flops / live_s / 1e12 / peak, 4),
+                         # split weights issue TWO matrix instructions per algorithmic multiply-add (W_hi and W_lo against the same activations):
+                         # `achieved` / `frac` count the ALGORITHMIC FLOPs (what the reference computes), these two the matrix pipe's actual work
+                         "mfma_issued_tflops": round(achieved * MFMA_PER_MAC.get(args.dtype, 1.0), 2),
+                         "frac_mfma_issued": round(achieved * MFMA_PER_MAC.get(args.dtype, 1.0) / peak, 4),
+                         "per_launch_roof": per_launch_roof,
                          # the bandwidth-side fraction, unfused activation traffic (380.6 MB/frame bf16 at 640x640) over 8 TB/s
                          "hbm_side_frac": round(fps / world * 380.6e6 / 8e12, 4) if (fh, fw, args.res, args.size) == (640, 640, 640, "c") else None,
                          "traffic": traffic, "traffic_note": traffic_note,
@@ -670,15 +727,16 @@ def main() -> None:
                                                "their sum (whole_step_tflops)",
                          "whole_step_tflops": round((alg_flops + stem_flops) * args.steps / elapsed / 1e12, 1),
                          "alg_gflop_per_step": round(alg_flops / 1e9, 2), "kernel_ms_per_step": round(conv_s * 1e3, 3),
-                         "kernel_ms_per_step_live": round(live_s * 1e3, 3),
-                         "kernel_ms_per_step_live_how": "whole step replayed as a hipGraph minus the non-conv launches replayed as a hipGraph, one hipEvent pair around "
-                                                        "10 replays each (the conv launches' time inside the plan, inter-kernel gaps included)"
-                                                        if g_all and g_other else "sum of per-launch hipEvent pairs (eager replay)",
+                         "kernel_ms_per_step_how": "whole step replayed as a hipGraph minus the non-conv launches replayed as a hipGraph, one hipEvent pair around "
+                                                   "10 replays each (the conv launches' time inside the plan, inter-kernel gaps included)"
+                                                   if g_all and g_other else "sum of per-launch hipEvent pairs (eager replay)",
                          "graph_ms": {"whole_step": round(g_all, 3), "non_conv_launches": round(g_other, 3), "conv_launches_alone": round(g_conv, 3)} if g_all else None,
                          "kernel_ms_per_step_eager_events": round(prof["conv_ms"], 3),
                          # the referee: rocprofv3's own kernel durations for the same launches (under the profiler the chip clocks ~2 % lower)
                          "kernel_ms_per_step_rocprofv3": round(traced["conv_ms_per_step"], 3) if traced else None,
                          "frac_rocprofv3": round(alg_flops / (traced["conv_ms_per_step"] * 1e-3) / 1e12 / peak, 4) if traced else None,
+                         "rocprofv3_record": ({k: traced.get(k) for k in ("tag", "dtype", "device_name", "kernel_source_digest")} if traced else
+                                              "no committed trace of these kernel sources / storage mode / device (profiles/kernel_trace.json)"),
                          "launches_per_step": prof["conv_launches"], "heaviest_launch": heaviest,
                          "other_ms_per_step": {k: round(prof[k], 3) for k in ("pool_ms", "decode_ms", "nms_ms", "stem_ms")},
                          "note": "stem_ms = stem_fused_kernel (letterbox + the 3->64 first conv straight from the uint8 frames, a byte/VALU-bound "
@@ -687,6 +745,8 @@ def main() -> None:
         }
         if median_100:
             line["median_100_steps"] = median_100
+        if latency is not None:
+            line["config"]["latency_ms_per_batch"] = latency
         # BASELINE.json configs[0] shape of call: one frame per call (the reference's batch-1 semantics), device-resident frame,
         # call-to-result latency including the (300,6) read-back
         try:
@@ -707,6 +767,18 @@ def main() -> None:
             line["streams"] = stream_side_metrics(local, args.size, args.res, args.dtype)
         if not args.no_clip and on_gpu:
             line["clip"] = clip_side_metrics(local, dev)
+            # the other metrics of BASELINE.json against their own roofs, inside `roofline` so every figure of the line has its fraction
+            try:
+                c = line["clip"]
+                q1 = c["search"]["one_gpu_1M_f32"]
+                line["roofline"]["other_metrics"] = {
+                    "clip_vit_l14_image_encode": {"bound": "mfma", "achieved": c["image_tflops"], "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                                  "frac": c["image_frac_of_mfma_peak"], "what": f"{c['image_embeds_per_sec']} img/s at batch {c['image_batch']} x 162.03 GFLOP, bf16, whole tower"},
+                    "search_scan_1M_f32": {"bound": "hbm", "achieved": q1["q1_end_to_end_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                           "frac": round(q1["q1_end_to_end_GBps"] * 1e9 / HBM_PEAK, 4),
+                                           "what": "1 M x 768 f32 rows (3.07 GB) / host-observed p50 latency of one query (upload + scan + top-k + read-back)"}}
+            except Exception:                     # noqa: BLE001
+                pass
         if streams_multi is not None:
             line["streams_multi_gpu"] = streams_multi
         if sharded is not None:

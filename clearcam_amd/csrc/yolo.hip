@@ -964,6 +964,8 @@ hipStream_t pool_stream_get(int device) {
 void pool_stream_put(int device, hipStream_t s) {
   if (!s) return;
   hipStreamSynchronize(s);
+  static const bool pooled = [] { const char* e = getenv("CLEARCAM_STREAM_POOL"); return !(e && atoi(e) == 0); }();
+  if (!pooled) { hipStreamDestroy(s); return; }          // CLEARCAM_STREAM_POOL=0: the round-3 behaviour, for A/B (tests/test_gpu_streams.py)
   std::lock_guard<std::mutex> lk(g_pool_mu);
   g_pool[device].push_back(s);
 }

@@ -8,15 +8,17 @@
 # and run the bench LAST (step 1 is executed after step 4 for that reason).
 set -u
 tag=${1:-r02d}
+export CLEARCAM_BENCH_DTYPE=${CLEARCAM_BENCH_DTYPE:-f16s}      # the storage mode every record below is taken in (bench.py's default)
+dt=$CLEARCAM_BENCH_DTYPE
 export TMPDIR=/tmp PYTHONPATH=$PWD
 root=$PWD
 mkdir -p gpurun_out
-CLEARCAM_PROFILE_CSV=$root/gpurun_out/${tag}_yolo_per_launch.csv python tools/dev/prof_csv.py 64 f16 > gpurun_out/${tag}_prof64.txt 2>&1
-CLEARCAM_PROFILE_CSV=$root/gpurun_out/${tag}_yolo_per_launch_b1.csv python tools/dev/prof_csv.py 1 f16 > gpurun_out/${tag}_prof1.txt 2>&1
+CLEARCAM_PROFILE_CSV=$root/gpurun_out/${tag}_yolo_per_launch.csv python tools/dev/prof_csv.py 64 $dt > gpurun_out/${tag}_prof64.txt 2>&1
+CLEARCAM_PROFILE_CSV=$root/gpurun_out/${tag}_yolo_per_launch_b1.csv python tools/dev/prof_csv.py 1 $dt > gpurun_out/${tag}_prof1.txt 2>&1
 (cd /tmp && rm -rf /tmp/kt_$tag && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$tag -o kt -- python $root/tools/dev/plan_passes.py 9 > $root/gpurun_out/${tag}_rocprof.log 2>&1)
 f=$(find /tmp/kt_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${tag}_yolo_kernel_stats.csv
-python tools/prof_summary.py /tmp/kt_$tag > gpurun_out/${tag}_yolo_f16_b64.txt 2>/dev/null
+python tools/prof_summary.py /tmp/kt_$tag > gpurun_out/${tag}_yolo_${dt}_b64.txt 2>/dev/null
 python - "$tag" <<'PY'
 import csv, json, os, sys
 from bench import kernel_source_digest
@@ -26,8 +28,11 @@ fam = lambda n: "conv" if ("conv" in n or "csp_fused" in n) else "stem" if "stem
 tot = {}
 for r in rows:
     tot[fam(r["Name"])] = tot.get(fam(r["Name"]), 0.0) + float(r["TotalDurationNs"]) / 1e6
-rec = {"kernel_source_digest": kernel_source_digest(), "tag": tag, "replays": 10,
-       "command": "rocprofv3 --kernel-trace --stats -- python tools/dev/plan_passes.py 9   (10 replays of the bench plan, YOLOv9-C f16 B=64 640x640)",
+import torch
+dt = os.environ.get("CLEARCAM_BENCH_DTYPE", "f16s")
+rec = {"kernel_source_digest": kernel_source_digest(), "tag": tag, "replays": 10, "dtype": dt,
+       "device_name": torch.cuda.get_device_name(0) if torch.cuda.is_available() else None,
+       "command": f"rocprofv3 --kernel-trace --stats -- python tools/dev/plan_passes.py 9   (10 replays of the bench plan, YOLOv9-C {dt} B=64 640x640)",
        "conv_ms_per_step": tot.get("conv", 0.0) / 10, "pool_ms_per_step": tot.get("pool", 0.0) / 10, "stem_ms_per_step": tot.get("stem", 0.0) / 10,
        "all_kernels_ms_per_step": sum(tot.values()) / 10}
 json.dump(rec, open("gpurun_out/kernel_trace.json", "w"), indent=1)
@@ -37,4 +42,4 @@ PY
 (cd /tmp && python $root/tools/pmc_traffic.py $tag > $root/gpurun_out/${tag}_pmc.log 2>&1)
 cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json 2>/dev/null
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
-tail -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_pmc.log | cut -c1-400; head -12 gpurun_out/${tag}_yolo_f16_b64.txt
+tail -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_pmc.log | cut -c1-400; head -12 gpurun_out/${tag}_yolo_${dt}_b64.txt
