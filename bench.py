@@ -77,10 +77,13 @@ def cpu_baseline(size: str, res: int, seconds: float = 10.0, with_clip: bool = T
     frames = np.random.default_rng(1).integers(0, 256, (8, res, res, 3), dtype=np.uint8)
     n1, t1 = _timed_loop(lambda: o(frames[0]), seconds)
     n8, t8 = _timed_loop(lambda: o.detect_batch(frames), seconds / 2)
-    # the thread count is a choice, so it is measured: the batch-1 detector at 16 / 64 / all usable threads (~2 s each); `value` keeps
-    # the default (CLEARCAM_CPU_THREADS or min(usable, 16)): one batch-1 conv stream does not scale past a few dozen threads
+    # the thread count is a choice, so it is measured: the batch-1 detector at 8 / 16 / 32 / 64 threads (~2 s each); `value` keeps the
+    # default (CLEARCAM_CPU_THREADS or min(usable, 16)).  One batch-1 conv stream does not scale: on the 256-thread GPU box 16 threads
+    # gave 12.8 frames/s, 64 threads 3.0 and all 256 threads 0.01 (one frame in 100 s; profiles/r04e_bench_line.json) - which is why
+    # the sweep stops at 64 (CLEARCAM_CPU_SWEEP="16,64,256" overrides)
     sweep = {}
-    for th in sorted({min(avail, t) for t in (16, 64, avail)}):
+    want = [int(t) for t in os.environ.get("CLEARCAM_CPU_SWEEP", "8,16,32,64").split(",") if t.strip()]
+    for th in sorted({min(avail, t) for t in want}):
         torch.set_num_threads(th)
         ns, ts = _timed_loop(lambda: o(frames[0]), 2.0)
         sweep[str(th)] = round(ns / ts, 3)
