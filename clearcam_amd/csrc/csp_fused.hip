@@ -41,8 +41,11 @@ template <int V> using IC = std::integral_constant<int, V>;
 template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(IC<I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <int HID> struct CspGeom {
+// SPLIT: every weight matrix is two f16 planes (ConvP::split; rows [tap: hi(Cin) | lo(Cin)]): twice the weight slabs, the same x / a / t /
+// u / b fragments walked once per plane, in the conv kernels' order (tap, plane, channel) - still bit-identical to the launches it replaces.
+template <int HID, bool SPLIT = false> struct CspGeom {
   static constexpr int C2 = 2 * HID, NSLAB = C2 / 64;                        // X / cv1|cv2 / cv3 K slabs of 64 channels
+  static constexpr int NSLABW = NSLAB * (SPLIT ? 2 : 1);                     // weight slabs of cv1|cv2 / cv3: [hi slabs | lo slabs]
   static constexpr int TH = 8, TW = 16, PW = TW + 4, PH = TH + 4, PR = PH * PW;   // 12 x 20 = 240 patch pixels
   static constexpr int QW = TW + 2, QH = TH + 2, QR = QH * QW;               // 10 x 18 = 180 ring pixels
   static constexpr int CPA = HID / 8;                                        // 16-byte chunks per row of A, B, T, U
@@ -57,26 +60,29 @@ template <int HID> struct CspGeom {
   static constexpr int X_BYTES = NSLAB * PR * 128, A_BYTES = 256 * PA, B_BYTES = 128 * PA, T_BYTES = 192 * PA, U_BYTES = 128 * PA;
   static constexpr int BIAS_BYTES = (2 * C2 + 2 * HID) * 4;                  // b12 | br | bb | b3 as f32
   static constexpr int SPC = HID == 64 ? 2 : 3;                              // streaming: 3x3 weight slabs per chunk
-  static constexpr int NS3 = (9 * HID + 63) / 64, NC3 = (NS3 + SPC - 1) / SPC;   // slabs / chunks per 3x3 stage: 9 / 5 and 5 / 2
+  // slabs / chunks per 3x3 stage: 9 / 5 (HID 64) and 5 / 2 (HID 32); split: a tap is [hi | lo] = two slabs at HID 64 (18 / 9), one at HID 32 (9 / 3)
+  static constexpr int NS3 = SPLIT ? (HID == 64 ? 18 : 9) : (9 * HID + 63) / 64, NC3 = (NS3 + SPC - 1) / SPC;
   static constexpr int SLAB_BIG = C2 * 128, SLAB_SMALL = HID * 128;          // bytes of a 64-wide K slab of cv1|cv2 / cv3 and of a 3x3
   static constexpr int RING = SLAB_BIG > SPC * SLAB_SMALL ? SLAB_BIG : SPC * SLAB_SMALL;
-  static constexpr int NCHUNK = 2 * NSLAB + 2 * NC3;
+  static constexpr int NCHUNK = 2 * NSLABW + 2 * NC3;
   // streaming layout: patch | A | B | two ring slots
   static constexpr int S_OFF_A = X_BYTES, S_OFF_B = S_OFF_A + A_BYTES, S_OFF_R = S_OFF_B + B_BYTES, S_OFF_BIAS = S_OFF_R + 2 * RING,
                        S_LDS_BYTES = (S_OFF_BIAS + BIAS_BYTES + 2047) & ~2047;
   // (sizes are rounded up to 2 KB: the tail of a dynamic-LDS request that is not a whole number of allocation granules is not
   //  addressable - reads of the last 256 bytes of a 150,272-byte request faulted on MI355X)
   // resident layout: two patch buffers | A | B | cv1|cv2 | rep 3x3 | 3x3 | cv3, slab by slab
-  static constexpr int R_OFF_A = 2 * X_BYTES, R_OFF_B = R_OFF_A + A_BYTES, R_OFF_W12 = R_OFF_B + B_BYTES, R_OFF_WR = R_OFF_W12 + NSLAB * SLAB_BIG,
-                       R_OFF_WB = R_OFF_WR + NS3 * SLAB_SMALL, R_OFF_W3 = R_OFF_WB + NS3 * SLAB_SMALL, R_OFF_BIAS = R_OFF_W3 + NSLAB * SLAB_BIG,
+  static constexpr int R_OFF_A = 2 * X_BYTES, R_OFF_B = R_OFF_A + A_BYTES, R_OFF_W12 = R_OFF_B + B_BYTES, R_OFF_WR = R_OFF_W12 + NSLABW * SLAB_BIG,
+                       R_OFF_WB = R_OFF_WR + NS3 * SLAB_SMALL, R_OFF_W3 = R_OFF_WB + NS3 * SLAB_SMALL, R_OFF_BIAS = R_OFF_W3 + NSLABW * SLAB_BIG,
                        R_LDS_BYTES = (R_OFF_BIAS + BIAS_BYTES + 2047) & ~2047;
   static_assert(T_BYTES + U_BYTES <= X_BYTES, "T and U alias the input patch");
 };
 
-template <class T, int HID, bool RES>
+template <class T, int HID, bool RES, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
-  using G = CspGeom<HID>;
-  constexpr int C2 = G::C2, NSLAB = G::NSLAB, PW = G::PW, PR = G::PR, QW = G::QW, QR = G::QR, CPA = G::CPA, PA = G::PA;
+  using G = CspGeom<HID, SPLIT>;
+  static_assert(!(RES && SPLIT), "split weights stream (two planes do not fit beside two patches)");
+  constexpr int C2 = G::C2, NSLAB = G::NSLAB, NSLABW = G::NSLABW, PW = G::PW, PR = G::PR, QW = G::QW, QR = G::QR, CPA = G::CPA, PA = G::PA;
+  const float os12 = SPLIT ? p.os12 : 1.0f, osr = SPLIT ? p.osr : 1.0f, osb = SPLIT ? p.osb : 1.0f, os3 = SPLIT ? p.os3 : 1.0f;   // exact 2^-e output scales
   constexpr int NJ1 = C2 / 16, NJ2 = HID / 32, SPC = G::SPC, NS3 = G::NS3, NC3 = G::NC3;
   constexpr int OFF_A = RES ? G::R_OFF_A : G::S_OFF_A, OFF_B = RES ? G::R_OFF_B : G::S_OFF_B, OFF_BIAS = RES ? G::R_OFF_BIAS : G::S_OFF_BIAS;
   constexpr int BI_12 = OFF_BIAS, BI_R = BI_12 + C2 * 4, BI_B = BI_R + HID * 4, BI_3 = BI_B + HID * 4;
@@ -149,10 +155,10 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
   auto issue_chunk = [&](auto k_c) {
     constexpr int K = decltype(k_c)::value;
     constexpr unsigned dst = G::S_OFF_R + (K & 1) * G::RING;
-    if constexpr (K < NSLAB) issue_w(p.w12, p.kw12, IC<C2>{}, K, IC<1>{}, dst);
-    else if constexpr (K < NSLAB + NC3) { constexpr int s0 = (K - NSLAB) * SPC; issue_w(p.wr, p.kwr, IC<HID>{}, s0, IC<(NS3 - s0 < SPC ? NS3 - s0 : SPC)>{}, dst); }
-    else if constexpr (K < NSLAB + 2 * NC3) { constexpr int s0 = (K - NSLAB - NC3) * SPC; issue_w(p.wb, p.kwb, IC<HID>{}, s0, IC<(NS3 - s0 < SPC ? NS3 - s0 : SPC)>{}, dst); }
-    else if constexpr (K < G::NCHUNK) issue_w(p.w3, p.kw3, IC<C2>{}, K - NSLAB - 2 * NC3, IC<1>{}, dst);
+    if constexpr (K < NSLABW) issue_w(p.w12, p.kw12, IC<C2>{}, K, IC<1>{}, dst);
+    else if constexpr (K < NSLABW + NC3) { constexpr int s0 = (K - NSLABW) * SPC; issue_w(p.wr, p.kwr, IC<HID>{}, s0, IC<(NS3 - s0 < SPC ? NS3 - s0 : SPC)>{}, dst); }
+    else if constexpr (K < NSLABW + 2 * NC3) { constexpr int s0 = (K - NSLABW - NC3) * SPC; issue_w(p.wb, p.kwb, IC<HID>{}, s0, IC<(NS3 - s0 < SPC ? NS3 - s0 : SPC)>{}, dst); }
+    else if constexpr (K < G::NCHUNK) issue_w(p.w3, p.kw3, IC<C2>{}, K - NSLABW - 2 * NC3, IC<1>{}, dst);
   };
   // Opens K slab SL of stage ST (0 cv1|cv2, 1 rep 3x3, 2 3x3, 3 cv3) and returns its LDS byte offset.
   // Streaming: at the first slab of a chunk wait for it, barrier (everything written to LDS before is visible, the other ring slot is
@@ -166,16 +172,17 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
       return ST == 0 ? G::R_OFF_W12 + SL * G::SLAB_BIG : ST == 1 ? G::R_OFF_WR + SL * G::SLAB_SMALL : ST == 2 ? G::R_OFF_WB + SL * G::SLAB_SMALL : G::R_OFF_W3 + SL * G::SLAB_BIG;
     } else {
       constexpr bool big = ST == 0 || ST == 3;
-      constexpr int K = ST == 0 ? SL : ST == 1 ? NSLAB + SL / SPC : ST == 2 ? NSLAB + NC3 + SL / SPC : NSLAB + 2 * NC3 + SL;
+      constexpr int K = ST == 0 ? SL : ST == 1 ? NSLABW + SL / SPC : ST == 2 ? NSLABW + NC3 + SL / SPC : NSLABW + 2 * NC3 + SL;
       constexpr int within = big ? 0 : (SL % SPC) * G::SLAB_SMALL;
       if constexpr ((big || SL % SPC == 0) && K > 0) { wait_vmcnt<0>(); __syncthreads(); issue_chunk(IC<K + 1>{}); }
       return G::S_OFF_R + (K & 1) * G::RING + within;
     }
   };
   // bias + SiLU of one accumulator fragment -> four storage-type values (8 bytes); `keep` false -> zeros (outside the image)
-  auto act4 = [&](const f32x4& av, int bias_off, bool keep) {
+  auto act4 = [&](const f32x4& av, float osc, int bias_off, bool keep) {
     const float4 b4 = *reinterpret_cast<const float4*>(ldsb + bias_off);
-    uint2 pk = make_uint2(pack2<T>(activate<T, 1>(av[0] + b4.x), activate<T, 1>(av[1] + b4.y)), pack2<T>(activate<T, 1>(av[2] + b4.z), activate<T, 1>(av[3] + b4.w)));
+    uint2 pk = make_uint2(pack2<T>(activate<T, 1>(__builtin_fmaf(av[0], osc, b4.x)), activate<T, 1>(__builtin_fmaf(av[1], osc, b4.y))),
+                          pack2<T>(activate<T, 1>(__builtin_fmaf(av[2], osc, b4.z)), activate<T, 1>(__builtin_fmaf(av[3], osc, b4.w))));
     if (!keep) pk = make_uint2(0u, 0u);
     return pk;
   };
@@ -200,7 +207,9 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
     constexpr int J = decltype(j_c)::value, NPX = decltype(npx_c)::value, SRCW = decltype(srcw_c)::value, NJ = decltype(nj_c)::value;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      const int tap = HID == 64 ? J : 2 * J + kh;                  // a 64-wide K slab is one tap (HID 64) or two (HID 32)
+      // a 64-wide K slab is one tap (HID 64) or two (HID 32); split: [hi | lo] of one tap (HID 32: the k halves read the SAME 32
+      // channels against the two planes) or one plane of one tap (HID 64: two slabs per tap)
+      const int tap = SPLIT ? (HID == 64 ? J / 2 : J) : (HID == 64 ? J : 2 * J + kh);
       if (tap < 9) {
         const int r = tap / 3, s = tap - r * 3;
         uint4 xf[NPX], wf[NJ];
@@ -255,14 +264,14 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
       int xrow[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) { const int row = 16 * (wave + 8 * i) + fr; xrow[i] = row < PR ? row : PR - 1; }   // fragment 15 is half empty: clamp
-      static_for<NSLAB>([&](auto s_c) {
-        constexpr int S = decltype(s_c)::value;
+      static_for<NSLABW>([&](auto s_c) {
+        constexpr int S = decltype(s_c)::value, XS = S % NSLAB;      // weight slab S multiplies x slab XS (split: the low plane walks x again)
         const int woff = open_slab(IC<0>{}, IC<S>{});
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
           uint4 xf[2], wf[NJ1];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const uint4*>(ldsb + x_off + S * (PR * 128) + xrow[i] * 128 + (((kh * 4 + fg) ^ swz<8>(xrow[i])) << 4));
+          for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const uint4*>(ldsb + x_off + XS * (PR * 128) + xrow[i] * 128 + (((kh * 4 + fg) ^ swz<8>(xrow[i])) << 4));
 #pragma unroll
           for (int j = 0; j < NJ1; ++j) { const int n = 16 * j + fr; wf[j] = *reinterpret_cast<const uint4*>(ldsb + woff + n * 128 + (((kh * 4 + fg) ^ swz<8>(n)) << 4)); }
 #pragma unroll
@@ -281,8 +290,8 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
 #pragma unroll
         for (int j = 0; j < NJ1; ++j) {
           const int n = 16 * j + 4 * fg;
-          if (j < HID / 16) *reinterpret_cast<uint2*>(ldsb + elem_off(OFF_A, row, n)) = act4(acc[j][i], BI_12 + n * 4, inimg);
-          else if (inner) *reinterpret_cast<uint2*>(ldsb + elem_off(OFF_B, q, n - HID)) = act4(acc[j][i], BI_12 + n * 4, true);
+          if (j < HID / 16) *reinterpret_cast<uint2*>(ldsb + elem_off(OFF_A, row, n)) = act4(acc[j][i], os12, BI_12 + n * 4, inimg);
+          else if (inner) *reinterpret_cast<uint2*>(ldsb + elem_off(OFF_B, q, n - HID)) = act4(acc[j][i], os12, BI_12 + n * 4, true);
         }
       }
     }
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
 #pragma unroll
           for (int jj = 0; jj < NJ2; ++jj) {
             const int n = (chh * NJ2 + jj) * 16 + 4 * fg;
-            *reinterpret_cast<uint2*>(ldsb + elem_off(off_t, q, n)) = act4(acc[jj][i], BI_R + n * 4, inimg);
+            *reinterpret_cast<uint2*>(ldsb + elem_off(off_t, q, n)) = act4(acc[jj][i], osr, BI_R + n * 4, inimg);
           }
         }
       }
@@ -353,8 +362,8 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
         const uint2 ru = *reinterpret_cast<const uint2*>(ldsb + elem_off(OFF_A, arow, n));
         const T* rt = reinterpret_cast<const T*>(&ru);
         *reinterpret_cast<uint2*>(ldsb + elem_off(off_u, qrow, n)) =
-            make_uint2(pack2<T>(to_f32<T>(rt[0]) + activate<T, 1>(av[0] + b4.x), to_f32<T>(rt[1]) + activate<T, 1>(av[1] + b4.y)),
-                       pack2<T>(to_f32<T>(rt[2]) + activate<T, 1>(av[2] + b4.z), to_f32<T>(rt[3]) + activate<T, 1>(av[3] + b4.w)));
+            make_uint2(pack2<T>(to_f32<T>(rt[0]) + activate<T, 1>(__builtin_fmaf(av[0], osb, b4.x)), to_f32<T>(rt[1]) + activate<T, 1>(__builtin_fmaf(av[1], osb, b4.y))),
+                       pack2<T>(to_f32<T>(rt[2]) + activate<T, 1>(__builtin_fmaf(av[2], osb, b4.z)), to_f32<T>(rt[3]) + activate<T, 1>(__builtin_fmaf(av[3], osb, b4.w))));
       }
     }
     if (p.dbg == 3) {
@@ -368,8 +377,8 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
     f32x4 acc4[NJ1][1];
 #pragma unroll
     for (int jj = 0; jj < NJ1; ++jj) acc4[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    static_for<NSLAB>([&](auto s_c) {
-      constexpr int S = decltype(s_c)::value;
+    static_for<NSLABW>([&](auto s_c) {
+      constexpr int S = decltype(s_c)::value % NSLAB;                          // the [u | b] slab this weight slab multiplies
       const int woff = open_slab(IC<3>{}, s_c);
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
 #pragma unroll
       for (int jj = 0; jj < NJ1; ++jj) {
         const int nl = 16 * jj + 4 * fg;
-        *reinterpret_cast<uint2*>(ldsb + (jj < NJ3 ? elem_off(off_u, qrow, nl) : elem_off(OFF_B, qrow, nl - HID))) = act4(acc4[jj][0], BI_3 + nl * 4, true);
+        *reinterpret_cast<uint2*>(ldsb + (jj < NJ3 ? elem_off(off_u, qrow, nl) : elem_off(OFF_B, qrow, nl - HID))) = act4(acc4[jj][0], os3, BI_3 + nl * 4, true);
       }
       T* outp = reinterpret_cast<T*>(p.out) + p.out_coff;
 #pragma unroll
@@ -406,32 +415,35 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
   }
 }
 
-bool csp_fused_supported(int dt, int hid) { return (dt == F16 || dt == BF16) && (hid == 32 || hid == 64); }
+bool csp_fused_supported(int dt, int hid, int split) { return (dt == F16 || (dt == BF16 && !split)) && (hid == 32 || hid == 64); }
 
-template <class T, int HID, bool RES> static void launch_csp(const CspP& p, hipStream_t stream) {
-  constexpr int lds = RES ? CspGeom<HID>::R_LDS_BYTES : CspGeom<HID>::S_LDS_BYTES;
+template <class T, int HID, bool RES, bool SPLIT = false> static void launch_csp(const CspP& p, hipStream_t stream) {
+  constexpr int lds = RES ? CspGeom<HID, SPLIT>::R_LDS_BYTES : CspGeom<HID, SPLIT>::S_LDS_BYTES;
   static PerDevice pd;                                 // attribute and CU count per device ordinal (common.h)
   const int pdi = pd.index();
   if (pd.first(pdi))
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csp_fused_kernel<T, HID, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(csp_fused_kernel<T, HID, RES, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int cus = pd.cu_count(pdi);
   const int total = p.B * p.tiles;
   // persistent: one block per CU, a multiple of 8 so that every XCD gets the same number of walkers
   const int grid = RES ? std::max(8, std::min(cus, total) & ~7) : total;
-  hipLaunchKernelGGL((csp_fused_kernel<T, HID, RES>), dim3(grid), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((csp_fused_kernel<T, HID, RES, SPLIT>), dim3(grid), dim3(512), lds, stream, p);
 }
 
 void launch_csp_fused(int dt, const CspP& p0, hipStream_t stream) {
-  CC_CHECK(csp_fused_supported(dt, p0.hid), "fused RepNCSP: 16-bit storage and hidden width 32 or 64 only");
+  CC_CHECK(csp_fused_supported(dt, p0.hid, p0.split), "fused RepNCSP: 16-bit storage (split weights: f16) and hidden width 32 or 64 only");
   CC_CHECK(p0.x_cstride % 8 == 0 && p0.x_coff % 8 == 0 && p0.out_cstride % 8 == 0 && p0.out_coff % 8 == 0 && (((uintptr_t)p0.x | (uintptr_t)p0.out) & 15) == 0,
            "fused RepNCSP: views must be 16-byte aligned");
-  CC_CHECK(p0.kw12 % 64 == 0 && p0.kw3 % 64 == 0 && p0.kwr % 64 == 0 && p0.kwb % 64 == 0 && p0.kwr >= 9 * p0.hid && p0.kwb >= 9 * p0.hid, "fused RepNCSP: weight rows must cover whole K slabs");
+  CC_CHECK(p0.kw12 % 64 == 0 && p0.kw3 % 64 == 0 && p0.kwr % 64 == 0 && p0.kwb % 64 == 0 && p0.kwr >= 9 * p0.hid * (1 + p0.split) && p0.kwb >= 9 * p0.hid * (1 + p0.split) &&
+           p0.kw12 >= 2 * p0.hid * (1 + p0.split) && p0.kw3 >= 2 * p0.hid * (1 + p0.split), "fused RepNCSP: weight rows must cover whole K slabs");
   CspP p = p0;
   p.tx = (p.W + 15) / 16; p.tiles = ((p.H + 7) / 8) * p.tx;
   p.inv_tiles = 1.0f / (float)p.tiles; p.inv_tx = 1.0f / (float)p.tx;
   CC_CHECK((long)p.B * p.tiles < (1L << 22), "fused RepNCSP: too many tiles");
   const bool res = p.hid == 32 && !p.stream;                        // 56 KB of weights stay in LDS; 208 KB (hidden 64) cannot
-  if (dt == F16) {
+  if (p.split) {                                                    // two weight planes: streamed at both widths
+    if (p.hid == 64) launch_csp<f16_t, 64, false, true>(p, stream); else launch_csp<f16_t, 32, false, true>(p, stream);
+  } else if (dt == F16) {
     if (p.hid == 64) launch_csp<f16_t, 64, false>(p, stream);
     else if (res) launch_csp<f16_t, 32, true>(p, stream); else launch_csp<f16_t, 32, false>(p, stream);
   } else {

@@ -366,10 +366,10 @@ struct Builder {
   bool fuse_csp(View in, int hid, int index) const {
     const char* e = getenv("CLEARCAM_FUSE_CSP");
     const int level = e ? atoi(e) : 2;
-    if (level == 0 || (level == 1 && hid != 32) || Y->wsplit) return false;    // the fused kernel holds one weight plane
+    if (level == 0 || (level == 1 && hid != 32)) return false;
     const char* only = dev_env("CLEARCAM_CSP_ONLY");                // development: fuse just this block (csp_debug.py)
     if (only && atoi(only) != index) return false;
-    return a.rep_n == 1 && csp_fused_supported(Y->dtype, hid) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0;
+    return a.rep_n == 1 && csp_fused_supported(Y->dtype, hid, Y->wsplit) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0;
   }
   void csp_fused(const std::string& r, View in, View out, int hid) {
     Op op{}; op.kind = 6; CspP& q = op.csp;
@@ -385,6 +385,7 @@ struct Builder {
     q.w12 = c12.w; q.kw12 = c12.kw; q.b12 = c12.bias; q.wr = cr.w; q.kwr = cr.kw; q.br = cr.bias;
     q.wb = cb.w; q.kwb = cb.kw; q.bb = cb.bias; q.w3 = c3.w; q.kw3 = c3.kw; q.b3 = c3.bias;
     q.B = P->B; q.H = ib.H; q.W = ib.W; q.hid = hid;
+    q.split = c12.split; q.os12 = c12.oscale; q.osr = cr.oscale; q.osb = cb.oscale; q.os3 = c3.oscale;
     { const char* e = dev_env("CLEARCAM_CSP_DBG"); q.dbg = e ? atoi(e) : 0; }       // stops the kernel after stage 1-3: WRONG outputs
     { const char* e = dev_env("CLEARCAM_CSP_STREAM"); q.stream = e ? atoi(e) : 0; }
     op.alg_macs = (double)P->B * ib.H * ib.W * (c12.macs_px + cr.macs_px + cb.macs_px + c3.macs_px);
