@@ -709,7 +709,12 @@ template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const Conv
     }
     launch_cfg<T, 128, SIMPLE>(p, a, M, g_cfg[0], g_cfg[1], stream);
   }
-  else if (bn == 64) launch_cfg<T, 64, SIMPLE>(p, a, M, g_cfg[2], g_cfg[3], stream);
+  else if (bn == 64) {
+    // deep K on 64-wide channel tiles (the DDetect box branch's 3x3 256 -> 64 / 512 -> 64 entry convs): three LDS stages, i.e. the DMA
+    // two K steps ahead - 206 us against 257 with two stages at 80x80, B = 64 (399 against 485 with split weights; r04c_head_split.txt)
+    const int ns64 = (sizeof(T) == 2 && g_cfg[3] == 2 && p.Ktot >= 2048) ? 3 : g_cfg[3];
+    launch_cfg<T, 64, SIMPLE>(p, a, M, g_cfg[2], ns64, stream);
+  }
   else launch_k<T, 128, 32, 4, SIMPLE, 8, 2>(p, a, (M + 127) / 128, stream);
 }
 

@@ -542,6 +542,17 @@ struct Builder {
     const std::string hb = H22 + "cv2.list." + std::to_string(l) + ".list.", hc = H22 + "cv3.list." + std::to_string(l) + ".list.";
     const int H = P->bufs[feat.buf].H, W = P->bufs[feat.buf].W, ch = a.cls_hidden;
     const int hbuf = new_buf(H, W, 64 + ch), bxb = new_buf(H, W, 64), clb = new_buf(H, W, ch);
+    // The level's two entry convs (box: feat -> 64, class: feat -> ch; yolov9.py:205-206) read the same map.  As ONE 64 + ch channel GEMM
+    // the input is read once - but 64 + 256 = 320 channels do not tile by 256, so the whole launch falls back to five 64-wide channel
+    // tiles that each pull the activations again.  With ch a multiple of 256 the class conv alone takes the eight-wave 256-wide
+    // kernel and the 64-channel box conv a launch of its own (cc_conv_bench, B = 64: 3x3 256 -> 320 at 80x80 857 us against 535 + 206,
+    // split weights 1495 against 935 + 399; profiles/r04c_head_split.txt).  Same K order per channel: the same bits either way.
+    // CLEARCAM_HEAD_SPLIT=0 keeps the single launch.
+    static const bool head_split_on = [] { const char* e = getenv("CLEARCAM_HEAD_SPLIT"); return !(e && atoi(e) == 0); }();
+    if (head_split_on && Y->dtype != F32 && ch % 256 == 0) {
+      conv({{feat, 0}}, pconv({hb + "0.conv"}, {1}), slice(whole(hbuf), 0, 64), 1, 1);
+      conv({{feat, 0}}, pconv({hc + "0.conv"}, {1}), slice(whole(hbuf), 64, ch), 1, 1);
+    } else
     conv({{feat, 0}}, pconv({hb + "0.conv", hc + "0.conv"}, {1, 1}), whole(hbuf), 1, 1);
     conv({{slice(whole(hbuf), 0, 64), 0}}, pconv({hb + "1.conv"}, {4}), whole(bxb), 1, 1);
     conv({{slice(whole(hbuf), 64, ch), 0}}, pconv({hc + "1.conv"}, {1}), whole(clb), 1, 1);

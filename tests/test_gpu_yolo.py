@@ -707,6 +707,24 @@ def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fu
     assert np.abs(a["p3"]).max() > 0.05 and np.isfinite(a["p3"]).all()
 
 
+@pytest.mark.parametrize("dtype", ["f16", "f16s"])
+def test_head_entry_split_equals_single_launch(tmp_path, dtype):
+    """DDetect's two entry convs per level (box 64 + class 256 channels over the same map) as two launches - the class conv on the
+    eight-wave 256-wide kernel - against the single 320-channel launch (CLEARCAM_HEAD_SPLIT=0): every channel's K walk is the same, so
+    the detections are IDENTICAL; three more conv launches per plan."""
+    import subprocess
+    import sys
+    outs = []
+    for on in ("0", "1"):
+        path = str(tmp_path / f"head{on}.npz")
+        env = dict(os.environ, CLEARCAM_HEAD_SPLIT=on, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", _CSP_SCRIPT, "c", "640", dtype, "640", "640", "3", path], check=True, env=env)
+        outs.append(np.load(path))
+    a, b = outs
+    assert int(b["launches"]) - int(a["launches"]) == 3
+    assert np.array_equal(a["det"], b["det"]) and (a["det"][..., 4] > 0).sum() > 10
+
+
 @pytest.mark.parametrize("size,res,dtype,shape", [
     ("c", 640, "f16", (3, 640, 640, 3)),          # the bench network: class branch 256 wide; 3 frames: ragged 64-pixel tiles at 20x20
     ("c", 640, "bf16", (2, 270, 480, 3)),         # letterboxed 384 x 640: non-square maps
