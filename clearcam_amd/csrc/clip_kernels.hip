@@ -157,32 +157,42 @@ void launch_l2norm(const NormP& p, hipStream_t stream) {
 }
 
 // ---- attention, 16-bit storage: S^T = K Q^T and O^T = V^T P^T on MFMA --------------------------------
-// One workgroup = (batch b, head h, 64 queries); wave w owns 16 queries.  The whole K (rows of 128 B, chunk-
-// swizzled like the GEMM tiles) and V^T (keys permuted so each PV operand is one 16-B read) of the head sit in
-// LDS: L <= 288 keys (ViT-L/14 has 257, the text tower 77) -> no online-softmax tiling over keys is needed.
-// Computing the TRANSPOSED scores puts one query per lane column (lane&15), so the softmax reduction is
-// 4*NF register values + two cross-lane steps, and the exponentiated P is already in MFMA B-operand layout.
-template <class T, int NF>    // NF = padded keys / 16
+// One workgroup = (image b, head h); wave w owns the 16-query tiles w, w+4, ...  The whole K (rows of 128 B, chunk-swizzled like
+// the GEMM tiles) and V (ROW-MAJOR, 160-byte rows) of the head sit in LDS: L <= 288 keys (ViT-L/14 has 257, the text tower 77) -> no
+// online-softmax tiling over keys is needed.  Computing the TRANSPOSED scores puts one query per lane column (lane&15), so the
+// softmax reduction is 4*NF register values + two cross-lane steps, and the exponentiated P is already in MFMA B-operand layout.
+//
+// Round 4: (1) V stays row-major and the PV A operand (V^T: eight keys of one output dimension per lane) is gathered by gfx950's
+// transposing LDS read - ds_read_b64_tr_b16: the sixteen lanes of a group point at the rows of a [4 keys][16 dims] block (lane i:
+// key i>>2, dims 4(i&3)..+3) and lane i receives dimension i of the four keys (checked on the chip: tools/dev/tr_read_test.hip).
+// Round 3 built V^T with 72 two-byte LDS writes per thread per (image, head) - banks 8-way conflicted (SQ_LDS_BANK_CONFLICT 8.8 % of
+// the kernel's wave cycles) - now nine 16-byte writes.  Row pitch 160 B: the eight rows a 32-lane half touches start 40 dwords
+// apart = eight distinct multiples of 8 banks (mod 64), i.e. conflict-free.  (2) K holds NFK <= NF fragments (17 for 257 keys), so
+// that two blocks still share a CU (80.9 KB each).  (3) With 257 = 16 x 16 + 1 queries the seventeenth tile holds ONE query, and as
+// wave 0's fifth tile it made every block 25 % longer than its waves' average: when tiles % 4 == 1 the last tile is computed by all
+// four waves, each over a quarter of the keys (local max / sum / partial O), merged through LDS (the K region, dead by then).
+template <class T> __device__ __forceinline__ uint2 lds_read_tr16(const T* p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <class T, int NF, int NFK>    // NF = padded keys / 16 (even: PV walks 32 keys per step); NFK = key fragments that can hold a real key
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   // two blocks per CU: one wave can run MFMAs while the other does its softmax
-  // padded keys; V^T row stride (elements).  A ds_read_b128 is served in lane groups that mix two neighbouring k-groups ({0-3, 12-15,
-  // 20-27}, ...): with a pitch of 6 (mod 16) sixteen-byte units - LP + 16 elements for both instantiations - rows of one k-group land on
-  // even units and the other's on odd ones.  LP + 8 (pitch 5 mod 16) had three two-way conflicts per group (SQ_LDS_BANK_CONFLICT was 13 %
-  // of the kernel's wave cycles).
-  constexpr int LP = NF * 16, VS = LP + 16;
-  static_assert((VS * 2 / 16) % 4 == 2, "V^T pitch must be 2 (mod 4) sixteen-byte units");
+  constexpr int LP = NF * 16, VP = 80;                                   // padded keys; V row pitch in elements (64 dims + 16: see above)
+  static_assert(NF % 2 == 0 && NFK <= NF && NFK >= NF - 1, "PV walks pairs of key fragments");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* ldsK = reinterpret_cast<uint4*>(smem);                         // [LP][8 chunks]
-  T* ldsVt = reinterpret_cast<T*>(smem + (size_t)LP * 128);             // [64][VS]
+  uint4* ldsK = reinterpret_cast<uint4*>(smem);                         // [NFK * 16][8 chunks]
+  T* ldsV = reinterpret_cast<T*>(smem + (size_t)NFK * 16 * 128);        // [LP][VP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, h = blockIdx.y;
   const int D3 = 3 * p.D;
   const T* base = reinterpret_cast<const T*>(p.qkv) + (size_t)b * p.L * D3 + h * 64;
 
-  // stage K and V^T of this (image, head) ONCE; the workgroup then walks all 64-query tiles.  All loads of a thread are issued
-  // before the first LDS write and none is conditional (keys past L are clamped and zeroed afterwards): with a load inside an
-  // `if (key < L)` per iteration hipcc branched around every load and waited for it before the next one - 2 x 9 dependent round
-  // trips per block (cdna_hip_programming.md, section 5, trap (c)).
-  {
+  // stage K and V of this (image, head) ONCE; the workgroup then walks all query tiles.  All loads of a thread are issued before the
+  // first LDS write and none is conditional (keys past L are clamped and zeroed afterwards): with a load inside an `if (key < L)` per
+  // iteration hipcc branched around every load and waited for it before the next one (cdna_hip_programming.md, section 5, trap (c)).
+  if (!(p.abl & 2)) {
     constexpr int NIT = LP * 8 / 256;
     static_assert(LP * 8 % 256 == 0, "whole passes of the 256 threads");
     uint4 kv[NIT], vv[NIT];
@@ -196,96 +206,155 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
     for (int it = 0; it < NIT; ++it) {
       const int idx = tid + 256 * it, key = idx >> 3, chunk = idx & 7;
       if (key >= p.L) { kv[it] = make_uint4(0, 0, 0, 0); vv[it] = make_uint4(0, 0, 0, 0); }
-      ldsK[key * 8 + (chunk ^ ((key >> 1) & 7))] = kv[it];
-      // key = 32f + 16hh + 4g + r  ->  position 32f + 8g + 4hh + r  (PV k-slot order, see below)
-      const int pos = (key & ~31) + ((key >> 2) & 3) * 8 + ((key >> 4) & 1) * 4 + (key & 3);
-      const T* ve = reinterpret_cast<const T*>(&vv[it]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ldsVt[(chunk * 8 + e) * VS + pos] = ve[e];
+      if (key < NFK * 16) ldsK[key * 8 + (chunk ^ ((key >> 1) & 7))] = kv[it];
+      *reinterpret_cast<uint4*>(ldsV + key * VP + chunk * 8) = vv[it];
     }
   }
   __syncthreads();
+  if (p.abl & 1) { if (tid == 0 && ldsK[0].x == 0x12345678u) reinterpret_cast<unsigned*>(p.ctx)[0] = 1u; return; }
   const int ql = lane & 15, g = lane >> 4;
-  // Q fragments are loaded one query tile AHEAD (unconditionally: rows past L re-read row L-1, their results are never stored): a
-  // wave otherwise opens every tile with a dependent global load and nothing to do while it is in flight - two waves per SIMD hide
-  // little (SQ counters: the kernel's waves were parked 52 % of their cycles).
-  uint4 qf[2], qn[2];
-  auto load_q = [&](int q0, uint4 (&dst)[2]) {
-    const int qc = q0 + ql < p.L ? q0 + ql : p.L - 1;
-  #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) dst[ks] = *reinterpret_cast<const uint4*>(base + (size_t)qc * D3 + (ks * 4 + g) * 8);
+  const float c = p.scale * 1.4426950408889634f;
+  // PV A operand of (32-key block f2, output-dimension block d): k slot (g, j): j < 4 -> key 32 f2 + 4g + j, j >= 4 -> key 32 f2 + 16 + 4g
+  // + (j - 4) - the order the scores sit in the registers - as two transposing reads of [4 keys][16 dims] blocks
+  const T* vbase = ldsV + (4 * g + (ql >> 2)) * VP + 4 * (ql & 3);
+  auto vfrag = [&](int f2, int d) {
+    const uint2 lo = lds_read_tr16(vbase + (f2 * 32) * VP + d * 16), hi = lds_read_tr16(vbase + (f2 * 32 + 16) * VP + d * 16);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
-  load_q(wave * 16, qf);
-  for (int q0 = wave * 16; q0 < p.L; q0 += 64) {
-    const int q = q0 + ql;
-    load_q(q0 + 64 < p.L ? q0 + 64 : q0, qn);
-
-    f32x4 s[NF];
-  #pragma unroll
-    for (int f = 0; f < NF; ++f) {
+  // scores of key fragments [F0, F1) against the query fragment qf: masked, exponentiated relative to the (returned) maximum over those
+  // keys; `sum` = the row sum of the exponentials.  s[f][r] = <k_{16f+4g+r}, q_{ql}>.  The softmax is the VALU-bound part of this
+  // kernel (72 values per lane against 72 MFMAs per tile), so it is kept to max / fma / v_exp_f32 / add per value: the row maximum is
+  // taken on the raw scores (scale > 0 keeps the order), scale*log2(e) is folded into one fma feeding the hardware exp2, and masking
+  // code runs only for fragments that actually contain padded or future keys.
+  auto scores = [&](const uint4 (&qf)[2], int q, auto f0_c, auto f1_c, f32x4 (&s)[NF], float& mx, float& sum) {
+    constexpr int F0 = decltype(f0_c)::value, F1 = decltype(f1_c)::value;
+#pragma unroll
+    for (int f = F0; f < F1; ++f) {
       s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-  #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int row = f * 16 + ql;
-        Mma<T>::run(ldsK[row * 8 + ((ks * 4 + g) ^ ((row >> 1) & 7))], qf[ks], s[f]);
+      if (f < NFK) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int row = f * 16 + ql;
+          Mma<T>::run(ldsK[row * 8 + ((ks * 4 + g) ^ ((row >> 1) & 7))], qf[ks], s[f]);
+        }
       }
-      if (f % 3 == 2) asm volatile("" ::: "memory");         // keep at most 6 K fragments in flight: hoisting all 36 reads costs 144 VGPRs
+      if ((f - F0) % 3 == 2) asm volatile("" ::: "memory");    // keep at most 6 K fragments in flight: hoisting all 36 reads costs 144 VGPRs
     }
-    // s[f][r] = <k_{16f+4g+r}, q_{ql}>.  The softmax is the VALU-bound part of this kernel (72 values per lane against
-    // 72 MFMAs per tile), so it is kept to max / fma / v_exp_f32 / add per value: the row maximum is taken on the raw
-    // scores (scale > 0 keeps the order), scale*log2(e) is folded into one fma feeding the hardware exp2, and masking
-    // code runs only for fragments that actually contain padded or future keys.
-    const float c = p.scale * 1.4426950408889634f;
-    float mx = -INFINITY;
-  #pragma unroll
-    for (int f = 0; f < NF; ++f) {
+    mx = -INFINITY;
+#pragma unroll
+    for (int f = F0; f < F1; ++f) {
       if (p.causal || f * 16 + 16 > p.L) {                     // wave-uniform
-  #pragma unroll
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = f * 16 + g * 4 + r;
           if (key >= p.L || (p.causal && key > q)) s[f][r] = -INFINITY;
         }
       }
-  #pragma unroll
+#pragma unroll
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mc = mx * c;
-    float sum = 0.f;
-  #pragma unroll
-    for (int f = 0; f < NF; ++f) {
+    const float mc = mx == -INFINITY ? 0.f : mx * c;            // a key range that is masked out entirely (split tile, causal): every p = 0
+    sum = 0.f;
+#pragma unroll
+    for (int f = F0; f < F1; ++f) {
       if (f * 16 >= p.L) { s[f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }      // fragment of padding only: p = 0
-  #pragma unroll
+#pragma unroll
       for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], c, -mc)); s[f][r] = e; sum += e; }
     }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-
-    f32x4 o[4];
-  #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  #pragma unroll
-    for (int f2 = 0; f2 < NF / 2; ++f2) {
-      // B operand k-slot (g, j): j<4 -> key 32f2 + 4g + j, j>=4 -> key 32f2 + 16 + 4g + (j-4); V^T was staged in that order
+  };
+  // O^T += V^T P^T over the 32-key blocks [B0, B1)
+  auto pv = [&](auto b0_c, auto b1_c, const f32x4 (&s)[NF], f32x4 (&o)[4]) {
+    constexpr int B0 = decltype(b0_c)::value, B1 = decltype(b1_c)::value;
+#pragma unroll
+    for (int f2 = B0; f2 < B1; ++f2) {
       const uint4 pf = make_uint4(pack2<T>(s[2 * f2][0], s[2 * f2][1]), pack2<T>(s[2 * f2][2], s[2 * f2][3]),
                                   pack2<T>(s[2 * f2 + 1][0], s[2 * f2 + 1][1]), pack2<T>(s[2 * f2 + 1][2], s[2 * f2 + 1][3]));
-  #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const uint4 vf = *reinterpret_cast<const uint4*>(ldsVt + (d * 16 + ql) * VS + f2 * 32 + g * 8);
-        Mma<T>::run(vf, pf, o[d]);
-      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) Mma<T>::run(vfrag(f2, d), pf, o[d]);
       if (f2 & 1) asm volatile("" ::: "memory");
     }
-    if (q < p.L) {
-      const float inv = 1.0f / sum;
-      T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q) * p.D + h * 64;
-  #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = make_uint2(pack2<T>(o[d][0] * inv, o[d][1] * inv), pack2<T>(o[d][2] * inv, o[d][3] * inv));
-      }
-    }
+  };
+  auto store_row = [&](int q, const f32x4 (&o)[4], float inv) {
+    T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q) * p.D + h * 64;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = make_uint2(pack2<T>(o[d][0] * inv, o[d][1] * inv), pack2<T>(o[d][2] * inv, o[d][3] * inv));
+  };
+
+  // Q fragments are loaded one query tile AHEAD (unconditionally: rows past L re-read row L-1, their results are never stored): a
+  // wave otherwise opens every tile with a dependent global load and nothing to do while it is in flight.
+  uint4 qf[2], qn[2];
+  auto load_q = [&](int q0, uint4 (&dst)[2]) {
+    const int qc = q0 + ql < p.L ? q0 + ql : p.L - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) dst[ks] = *reinterpret_cast<const uint4*>(base + (size_t)qc * D3 + (ks * 4 + g) * 8);
+  };
+  const int tiles = (p.L + 15) >> 4;
+  const bool split_last = (tiles & 3) == 1 && tiles > 1;         // block-uniform: the last tile is shared by the four waves
+  const int own_end = (split_last ? tiles - 1 : tiles) * 16;     // queries below this belong to whole-tile rounds
+  load_q(wave * 16, qf);
+  for (int q0 = wave * 16; q0 < own_end; q0 += 64) {
+    const int q = q0 + ql;
+    load_q(q0 + 64 < own_end ? q0 + 64 : (split_last ? (tiles - 1) * 16 : q0), qn);
+    f32x4 s[NF];
+    float mx, sum;
+    scores(qf, q, std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{}, s, mx, sum);
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pv(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{}, s, o);
+    if (q < p.L) store_row(q, o, 1.0f / sum);
     qf[0] = qn[0]; qf[1] = qn[1];
+  }
+  if (!split_last) return;
+  // ---- the last tile, key range split four ways: wave w takes the 32-key blocks [BLK0(w), BLK0(w+1)) ------------------------------------
+  constexpr int NB = NF / 2, BQ = NB / 4, BR = NB % 4;             // 9 blocks -> 3, 2, 2, 2
+  {
+    const int q0 = (tiles - 1) * 16, q = q0 + ql;
+    if (wave * 16 >= own_end) load_q(q0, qf);                      // a wave that ran no whole tile (L <= 64) has not prefetched it
+    f32x4 s[NF], o[4];
+    float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto part = [&](auto w_c) {
+      constexpr int W = decltype(w_c)::value, B0 = W * BQ + (W < BR ? W : BR), B1 = B0 + BQ + (W < BR ? 1 : 0);
+      scores(qf, q, std::integral_constant<int, 2 * B0>{}, std::integral_constant<int, 2 * B1>{}, s, mx, sum);
+      pv(std::integral_constant<int, B0>{}, std::integral_constant<int, B1>{}, s, o);
+    };
+    if (wave == 0) part(std::integral_constant<int, 0>{});
+    else if (wave == 1) part(std::integral_constant<int, 1>{});
+    else if (wave == 2) part(std::integral_constant<int, 2>{});
+    else part(std::integral_constant<int, 3>{});
+    __syncthreads();                                               // nobody reads K any more: its region takes the partial results
+    float* part_o = reinterpret_cast<float*>(smem);                // [4 waves][4 d][64 lanes] float4  = 16 KB
+    float* part_ms = part_o + 4 * 4 * 64 * 4;                      // [4 waves][16 queries][2]
+#pragma unroll
+    for (int d = 0; d < 4; ++d) *reinterpret_cast<float4*>(part_o + ((wave * 4 + d) * 64 + lane) * 4) = make_float4(o[d][0], o[d][1], o[d][2], o[d][3]);
+    if (g == 0) { part_ms[(wave * 16 + ql) * 2] = mx; part_ms[(wave * 16 + ql) * 2 + 1] = sum; }
+    __syncthreads();
+    // wave w merges output-dimension block d = w of every query of the tile: o = sum_w o_w 2^((m_w - m) c) / sum_w l_w 2^((m_w - m) c)
+    float m = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) m = fmaxf(m, part_ms[(w * 16 + ql) * 2]);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float mw = part_ms[(w * 16 + ql) * 2];
+      const float fac = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((mw - m) * c);
+      l += part_ms[(w * 16 + ql) * 2 + 1] * fac;
+      const float4 ow = *reinterpret_cast<const float4*>(part_o + ((w * 4 + wave) * 64 + lane) * 4);
+      acc[0] += ow.x * fac; acc[1] += ow.y * fac; acc[2] += ow.z * fac; acc[3] += ow.w * fac;
+    }
+    if (q < p.L) {
+      const float inv = 1.0f / l;
+      T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q) * p.D + h * 64;
+      *reinterpret_cast<uint2*>(out + wave * 16 + g * 4) = make_uint2(pack2<T>(acc[0] * inv, acc[1] * inv), pack2<T>(acc[2] * inv, acc[3] * inv));
+    }
   }
 }
 
@@ -324,13 +393,20 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(const AttnP p) {
   if (live) reinterpret_cast<T*>(p.ctx)[((size_t)b * p.L + q) * p.D + h * 64 + lane] = from_f32<T>(o);
 }
 
-template <class T, int NF> static void launch_attn_mfma(const AttnP& p, hipStream_t stream) {
-  const size_t lds = (size_t)NF * 16 * 128 + (size_t)64 * (NF * 16 + 16) * sizeof(T);
+template <class T, int NF, int NFK> static void launch_attn_mfma(const AttnP& p, hipStream_t stream) {
+  const size_t lds = std::max((size_t)NFK * 16 * 128, (size_t)(4 * 4 * 64 * 4 + 4 * 16 * 2) * 4) + (size_t)NF * 16 * 80 * sizeof(T);
   static PerDevice once;                               // the attribute is per device (common.h)
   if (once.first(once.index())) {
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<T, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<T, NF, NFK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((attn_mfma_kernel<T, NF>), dim3(1, p.H, p.B), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((attn_mfma_kernel<T, NF, NFK>), dim3(1, p.H, p.B), dim3(256), lds, stream, p);
+}
+template <class T> static void launch_attn_t(const AttnP& p, hipStream_t stream) {
+  // K keeps only the fragments that can hold a real key: 17 of 18 for 257 keys (two blocks per CU need <= 80 KB each)
+  if (p.L <= 80) launch_attn_mfma<T, 6, 5>(p, stream);
+  else if (p.L <= 96) launch_attn_mfma<T, 6, 6>(p, stream);
+  else if (p.L <= 272) launch_attn_mfma<T, 18, 17>(p, stream);
+  else launch_attn_mfma<T, 18, 18>(p, stream);
 }
 
 void launch_attention(int dt, const AttnP& p, hipStream_t stream) {
@@ -338,11 +414,8 @@ void launch_attention(int dt, const AttnP& p, hipStream_t stream) {
   CC_CHECK(p.L <= 288, "attention: more than 288 tokens");
   if (dt == F32) {
     hipLaunchKernelGGL(attn_simple_kernel<float>, dim3((p.L + 3) / 4, p.H, p.B), dim3(256), 0, stream, p);
-  } else if (dt == F16) {
-    if (p.L <= 96) launch_attn_mfma<f16_t, 6>(p, stream); else launch_attn_mfma<f16_t, 18>(p, stream);
-  } else {
-    if (p.L <= 96) launch_attn_mfma<bf16_t, 6>(p, stream); else launch_attn_mfma<bf16_t, 18>(p, stream);
-  }
+  } else if (dt == F16) launch_attn_t<f16_t>(p, stream);
+  else launch_attn_t<bf16_t>(p, stream);
   CC_HIP(hipGetLastError());
 }
 

@@ -1380,6 +1380,35 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
   CC_API_END
 }
 
+// Diagnostic: average device time of one attention launch over random 16-bit data (kernel tuning; abl as AttnP::abl).
+int cc_attn_bench(int dtype, int B, int L, int H, int causal, int abl, int iters, float* ms) {
+  CC_API_BEGIN
+  CC_CHECK(ms && iters > 0 && (dtype == F16 || dtype == BF16) && B > 0 && L > 0 && H > 0, "bad argument");
+  const int D = H * 64;
+  const size_t nq = (size_t)B * L * 3 * D, no = (size_t)B * L * D;
+  std::vector<float> hx(std::min<size_t>(nq, (size_t)1 << 22));
+  uint32_t st = 777u;
+  for (auto& v : hx) { st = st * 1664525u + 1013904223u; v = ((st >> 8) & 0xffff) / 65536.0f - 0.5f; }
+  std::vector<char> h16(hx.size() * 2);
+  convert_f32_to(dtype, hx.data(), h16.data(), hx.size());
+  char *qkv = nullptr, *ctx = nullptr;
+  CC_HIP(hipMalloc((void**)&qkv, nq * 2 + 256)); CC_HIP(hipMalloc((void**)&ctx, no * 2 + 256));
+  for (size_t off = 0; off < nq * 2; off += h16.size()) CC_HIP(hipMemcpy(qkv + off, h16.data(), std::min(h16.size(), nq * 2 - off), hipMemcpyHostToDevice));
+  AttnP a{}; a.qkv = qkv; a.ctx = ctx; a.B = B; a.L = L; a.H = H; a.D = D; a.causal = causal; a.scale = 0.125f; a.abl = abl;
+  hipStream_t s; CC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t e0, e1; CC_HIP(hipEventCreate(&e0)); CC_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) launch_attention(dtype, a, s);
+  CC_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) launch_attention(dtype, a, s);
+  CC_HIP(hipEventRecord(e1, s));
+  CC_HIP(hipStreamSynchronize(s));
+  float t = 0; CC_HIP(hipEventElapsedTime(&t, e0, e1));
+  *ms = t / iters;
+  hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+  hipFree(qkv); hipFree(ctx);
+  CC_API_END
+}
+
 int cc_round_weights_feedback(int dtype, const float* w, int64_t cout, int64_t per_channel, float* out) {
   CC_API_BEGIN
   CC_CHECK(w && out && cout >= 0 && per_channel >= 0 && (dtype == F16 || dtype == BF16), "bad argument (dtype 1 = f16 or 2 = bf16)");

@@ -97,6 +97,9 @@ int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, c
 /* Diagnostic (kernel tuning, tools/dev/phase_ab.py): average device milliseconds of one launch of the conv above on random
  * 16-bit data resident in HBM, weights packed once, `iters` launches between two events.  Not part of the drop-in surface. */
 int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int variant, int iters, float* ms);
+/* Diagnostic (kernel tuning, tools/dev/attn_ab.py): average device milliseconds of one attention launch (B images, L tokens, H heads of 64)
+ * on random 16-bit data; abl: 0 the kernel, 1 K / V staging only, 2 tiles without staging.  Not part of the drop-in surface. */
+int cc_attn_bench(int dtype, int B, int L, int H, int causal, int abl, int iters, float* ms);
 /* Host-only helper (no GPU needed; tests / tooling): the error-feedback rounding cc_yolo_finalize applies to a conv's OIHW float32
  * weights for the plain 16-bit storage types (dtype 1 / 2) - along each of the `cout` output channels (`per_channel` = Cin*kh*kw
  * weights each) the rounding residual of a weight is added to the next one before it is rounded.  out[i] = the value the storage
