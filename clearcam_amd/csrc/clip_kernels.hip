@@ -177,7 +177,14 @@ template <class T> __device__ __forceinline__ uint2 lds_read_tr16(const T* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <class T, int NF, int NFK>    // NF = padded keys / 16 (even: PV walks 32 keys per step); NFK = key fragments that can hold a real key
+// LFULL >= 0: the token count is known at compile time to the extent that matters - fragments below LFULL hold real keys only, fragment
+// LFULL is the partial one (keys >= L masked), fragments above it are padding - and CAUSAL is a compile-time flag: the score / softmax
+// section is then straight-line code.  With L and causal as run-time values it compiled to ~130 wave-uniform branches and 220 s_waitcnt
+// per tile pair (every fragment asks "do I need masking?", "am I padding?") and ran at a third of the speed (round 4: the softmax section
+// alone took 124 of the kernel's 225 us at ViT-L/14's shape, cc_attn_bench ablations).  LFULL = -1 keeps the run-time form for other lengths.
+// NQ = query tiles a wave works on at once (1 or 2): with two, every K / V fragment read from LDS feeds two MFMAs and the two tiles'
+// dependent chains (36 MFMAs -> max -> 72 exp -> 36 MFMAs) interleave - the kernel is bound by those latencies, not by instruction issue.
+template <class T, int NF, int NFK, int LFULL = -1, int CAUSAL = -1, int NQ = 1>    // NF = padded keys / 16 (even: PV walks 32 keys per step); NFK = key fragments that can hold a real key
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   // two blocks per CU: one wave can run MFMAs while the other does its softmax
   constexpr int LP = NF * 16, VP = 80;                                   // padded keys; V row pitch in elements (64 dims + 16: see above)
   static_assert(NF % 2 == 0 && NFK <= NF && NFK >= NF - 1, "PV walks pairs of key fragments");
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
   }
   __syncthreads();
   if (p.abl & 1) { if (tid == 0 && ldsK[0].x == 0x12345678u) reinterpret_cast<unsigned*>(p.ctx)[0] = 1u; return; }
+  if (p.abl & 32) return;
   const int ql = lane & 15, g = lane >> 4;
   const float c = p.scale * 1.4426950408889634f;
   // PV A operand of (32-key block f2, output-dimension block d): k slot (g, j): j < 4 -> key 32 f2 + 4g + j, j >= 4 -> key 32 f2 + 16 + 4g
@@ -226,55 +234,78 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
   // kernel (72 values per lane against 72 MFMAs per tile), so it is kept to max / fma / v_exp_f32 / add per value: the row maximum is
   // taken on the raw scores (scale > 0 keeps the order), scale*log2(e) is folded into one fma feeding the hardware exp2, and masking
   // code runs only for fragments that actually contain padded or future keys.
-  auto scores = [&](const uint4 (&qf)[2], int q, auto f0_c, auto f1_c, f32x4 (&s)[NF], float& mx, float& sum) {
-    constexpr int F0 = decltype(f0_c)::value, F1 = decltype(f1_c)::value;
+  // (the lambdas below take the number of query tiles NT <= NQ they work on as a compile-time argument: NQ in the main loop, 1 in the split tile)
+  auto scores = [&](auto nt_c, const uint4 (&qf)[NQ][2], const int (&q)[NQ], auto f0_c, auto f1_c, f32x4 (&s)[NQ][NF], float (&mx)[NQ], float (&sum)[NQ]) {
+    constexpr int NT = decltype(nt_c)::value, F0 = decltype(f0_c)::value, F1 = decltype(f1_c)::value;
+    constexpr bool RT = LFULL < 0;                              // run-time token count / causal flag
+    const bool causal = RT ? (p.causal != 0) : (CAUSAL != 0);
 #pragma unroll
     for (int f = F0; f < F1; ++f) {
-      s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (f < NFK) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) s[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (f < NFK && (RT || f <= LFULL)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const int row = f * 16 + ql;
-          Mma<T>::run(ldsK[row * 8 + ((ks * 4 + g) ^ ((row >> 1) & 7))], qf[ks], s[f]);
+          const uint4 kf = ldsK[row * 8 + ((ks * 4 + g) ^ ((row >> 1) & 7))];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) Mma<T>::run(kf, qf[t][ks], s[t][f]);
         }
       }
       if ((f - F0) % 3 == 2) asm volatile("" ::: "memory");    // keep at most 6 K fragments in flight: hoisting all 36 reads costs 144 VGPRs
     }
-    mx = -INFINITY;
 #pragma unroll
-    for (int f = F0; f < F1; ++f) {
-      if (p.causal || f * 16 + 16 > p.L) {                     // wave-uniform
+    for (int t = 0; t < NT; ++t) {
+      float m_ = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = f * 16 + g * 4 + r;
-          if (key >= p.L || (p.causal && key > q)) s[f][r] = -INFINITY;
+      for (int f = F0; f < F1; ++f) {
+        if (!RT && f > LFULL) continue;                        // padding only: out of the maximum and the sum, p = 0
+        if (RT ? (causal || f * 16 + 16 > p.L) : (CAUSAL != 0 || f == LFULL)) {   // run time: wave-uniform branch; compile time: no branch
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = f * 16 + g * 4 + r;
+            const bool dead = ((RT || f == LFULL) && key >= p.L) || (causal && key > q[t]);
+            s[t][f][r] = dead ? -INFINITY : s[t][f][r];
+          }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m_ = fmaxf(m_, s[t][f][r]);
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][r]);
+      m_ = fmaxf(m_, __shfl_xor(m_, 16, 64));
+      m_ = fmaxf(m_, __shfl_xor(m_, 32, 64));
+      mx[t] = m_;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mc = mx == -INFINITY ? 0.f : mx * c;            // a key range that is masked out entirely (split tile, causal): every p = 0
-    sum = 0.f;
 #pragma unroll
-    for (int f = F0; f < F1; ++f) {
-      if (f * 16 >= p.L) { s[f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }      // fragment of padding only: p = 0
+    for (int t = 0; t < NT; ++t) {
+      const float mc = mx[t] == -INFINITY ? 0.f : mx[t] * c;    // a key range that is masked out entirely (split tile, causal): every p = 0
+      float l_ = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], c, -mc)); s[f][r] = e; sum += e; }
+      for (int f = F0; f < F1; ++f) {
+        if (RT ? (f * 16 >= p.L) : (f > LFULL)) { s[t][f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }      // fragment of padding only: p = 0
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][f][r], c, -mc)); s[t][f][r] = e; l_ += e; }
+      }
+      l_ += __shfl_xor(l_, 16, 64);
+      l_ += __shfl_xor(l_, 32, 64);
+      sum[t] = l_;
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
   };
   // O^T += V^T P^T over the 32-key blocks [B0, B1)
-  auto pv = [&](auto b0_c, auto b1_c, const f32x4 (&s)[NF], f32x4 (&o)[4]) {
-    constexpr int B0 = decltype(b0_c)::value, B1 = decltype(b1_c)::value;
+  auto pv = [&](auto nt_c, auto b0_c, auto b1_c, const f32x4 (&s)[NQ][NF], f32x4 (&o)[NQ][4]) {
+    constexpr int NT = decltype(nt_c)::value, B0 = decltype(b0_c)::value, B1 = decltype(b1_c)::value;
 #pragma unroll
     for (int f2 = B0; f2 < B1; ++f2) {
-      const uint4 pf = make_uint4(pack2<T>(s[2 * f2][0], s[2 * f2][1]), pack2<T>(s[2 * f2][2], s[2 * f2][3]),
-                                  pack2<T>(s[2 * f2 + 1][0], s[2 * f2 + 1][1]), pack2<T>(s[2 * f2 + 1][2], s[2 * f2 + 1][3]));
+      uint4 pf[NT];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) Mma<T>::run(vfrag(f2, d), pf, o[d]);
+      for (int t = 0; t < NT; ++t)
+        pf[t] = make_uint4(pack2<T>(s[t][2 * f2][0], s[t][2 * f2][1]), pack2<T>(s[t][2 * f2][2], s[t][2 * f2][3]),
+                           pack2<T>(s[t][2 * f2 + 1][0], s[t][2 * f2 + 1][1]), pack2<T>(s[t][2 * f2 + 1][2], s[t][2 * f2 + 1][3]));
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint4 vf = vfrag(f2, d);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) Mma<T>::run(vf, pf[t], o[t][d]);
+      }
       if (f2 & 1) asm volatile("" ::: "memory");
     }
   };
@@ -285,9 +316,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
       *reinterpret_cast<uint2*>(out + d * 16 + g * 4) = make_uint2(pack2<T>(o[d][0] * inv, o[d][1] * inv), pack2<T>(o[d][2] * inv, o[d][3] * inv));
   };
 
-  // Q fragments are loaded one query tile AHEAD (unconditionally: rows past L re-read row L-1, their results are never stored): a
+  // Q fragments are loaded one round AHEAD (unconditionally: rows past L re-read row L-1, their results are never stored): a
   // wave otherwise opens every tile with a dependent global load and nothing to do while it is in flight.
-  uint4 qf[2], qn[2];
+  uint4 qf[NQ][2], qn[NQ][2];
   auto load_q = [&](int q0, uint4 (&dst)[2]) {
     const int qc = q0 + ql < p.L ? q0 + ql : p.L - 1;
 #pragma unroll
@@ -296,34 +327,49 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
   const int tiles = (p.L + 15) >> 4;
   const bool split_last = (tiles & 3) == 1 && tiles > 1;         // block-uniform: the last tile is shared by the four waves
   const int own_end = (split_last ? tiles - 1 : tiles) * 16;     // queries below this belong to whole-tile rounds
-  load_q(wave * 16, qf);
-  for (int q0 = wave * 16; q0 < own_end; q0 += 64) {
-    const int q = q0 + ql;
-    load_q(q0 + 64 < own_end ? q0 + 64 : (split_last ? (tiles - 1) * 16 : q0), qn);
-    f32x4 s[NF];
-    float mx, sum;
-    scores(qf, q, std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{}, s, mx, sum);
-    f32x4 o[4];
+  // round i of wave w: tiles w + 4 (NQ i + t), t < NQ (the launcher picks NQ = 2 only when the whole-tile rounds come in pairs)
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    pv(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{}, s, o);
-    if (q < p.L) store_row(q, o, 1.0f / sum);
-    qf[0] = qn[0]; qf[1] = qn[1];
+  for (int t = 0; t < NQ; ++t) load_q(wave * 16 + 64 * t, qf[t]);
+  for (int q0 = wave * 16; q0 < own_end; q0 += 64 * NQ) {
+    int q[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) q[t] = q0 + 64 * t + ql;
+    const bool more = q0 + 64 * NQ < own_end;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) load_q(more ? q0 + 64 * (NQ + t) : (split_last ? (tiles - 1) * 16 : q0), qn[t]);
+    f32x4 s[NQ][NF];
+    float mx[NQ], sum[NQ];
+    scores(std::integral_constant<int, NQ>{}, qf, q, std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{}, s, mx, sum);
+    f32x4 o[NQ][4];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pv(std::integral_constant<int, NQ>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{}, s, o);
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      if (q[t] < p.L) store_row(q[t], o[t], 1.0f / sum[t]);
+      qf[t][0] = qn[t][0]; qf[t][1] = qn[t][1];
+    }
   }
   if (!split_last) return;
   // ---- the last tile, key range split four ways: wave w takes the 32-key blocks [BLK0(w), BLK0(w+1)) ------------------------------------
   constexpr int NB = NF / 2, BQ = NB / 4, BR = NB % 4;             // 9 blocks -> 3, 2, 2, 2
   {
-    const int q0 = (tiles - 1) * 16, q = q0 + ql;
-    if (wave * 16 >= own_end) load_q(q0, qf);                      // a wave that ran no whole tile (L <= 64) has not prefetched it
-    f32x4 s[NF], o[4];
-    float mx = -INFINITY, sum = 0.f;
+    const int q0 = (tiles - 1) * 16;
+    int q[NQ];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NQ; ++t) q[t] = q0 + ql;
+    if (wave * 16 >= own_end) load_q(q0, qf[0]);                   // a wave that ran no whole tile (L <= 64) has not prefetched it
+    f32x4 s[NQ][NF], o[NQ][4];
+    float mx[NQ], sum[NQ];
+    mx[0] = -INFINITY; sum[0] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[0][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto part = [&](auto w_c) {
       constexpr int W = decltype(w_c)::value, B0 = W * BQ + (W < BR ? W : BR), B1 = B0 + BQ + (W < BR ? 1 : 0);
-      scores(qf, q, std::integral_constant<int, 2 * B0>{}, std::integral_constant<int, 2 * B1>{}, s, mx, sum);
-      pv(std::integral_constant<int, B0>{}, std::integral_constant<int, B1>{}, s, o);
+      scores(std::integral_constant<int, 1>{}, qf, q, std::integral_constant<int, 2 * B0>{}, std::integral_constant<int, 2 * B1>{}, s, mx, sum);
+      pv(std::integral_constant<int, 1>{}, std::integral_constant<int, B0>{}, std::integral_constant<int, B1>{}, s, o);
     };
     if (wave == 0) part(std::integral_constant<int, 0>{});
     else if (wave == 1) part(std::integral_constant<int, 1>{});
@@ -333,8 +379,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
     float* part_o = reinterpret_cast<float*>(smem);                // [4 waves][4 d][64 lanes] float4  = 16 KB
     float* part_ms = part_o + 4 * 4 * 64 * 4;                      // [4 waves][16 queries][2]
 #pragma unroll
-    for (int d = 0; d < 4; ++d) *reinterpret_cast<float4*>(part_o + ((wave * 4 + d) * 64 + lane) * 4) = make_float4(o[d][0], o[d][1], o[d][2], o[d][3]);
-    if (g == 0) { part_ms[(wave * 16 + ql) * 2] = mx; part_ms[(wave * 16 + ql) * 2 + 1] = sum; }
+    for (int d = 0; d < 4; ++d) *reinterpret_cast<float4*>(part_o + ((wave * 4 + d) * 64 + lane) * 4) = make_float4(o[0][d][0], o[0][d][1], o[0][d][2], o[0][d][3]);
+    if (g == 0) { part_ms[(wave * 16 + ql) * 2] = mx[0]; part_ms[(wave * 16 + ql) * 2 + 1] = sum[0]; }
     __syncthreads();
     // wave w merges output-dimension block d = w of every query of the tile: o = sum_w o_w 2^((m_w - m) c) / sum_w l_w 2^((m_w - m) c)
     float m = -INFINITY;
@@ -350,9 +396,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnP p) {   //
       const float4 ow = *reinterpret_cast<const float4*>(part_o + ((w * 4 + wave) * 64 + lane) * 4);
       acc[0] += ow.x * fac; acc[1] += ow.y * fac; acc[2] += ow.z * fac; acc[3] += ow.w * fac;
     }
-    if (q < p.L) {
+    if (q[0] < p.L) {
       const float inv = 1.0f / l;
-      T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q) * p.D + h * 64;
+      T* out = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.L + q[0]) * p.D + h * 64;
       *reinterpret_cast<uint2*>(out + wave * 16 + g * 4) = make_uint2(pack2<T>(acc[0] * inv, acc[1] * inv), pack2<T>(acc[2] * inv, acc[3] * inv));
     }
   }
@@ -393,16 +439,27 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(const AttnP p) {
   if (live) reinterpret_cast<T*>(p.ctx)[((size_t)b * p.L + q) * p.D + h * 64 + lane] = from_f32<T>(o);
 }
 
-template <class T, int NF, int NFK> static void launch_attn_mfma(const AttnP& p, hipStream_t stream) {
+template <class T, int NF, int NFK, int LFULL = -1, int CAUSAL = -1, int NQ = 1> static void launch_attn_mfma(const AttnP& p, hipStream_t stream) {
   const size_t lds = std::max((size_t)NFK * 16 * 128, (size_t)(4 * 4 * 64 * 4 + 4 * 16 * 2) * 4) + (size_t)NF * 16 * 80 * sizeof(T);
   static PerDevice once;                               // the attribute is per device (common.h)
   if (once.first(once.index())) {
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<T, NF, NFK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<T, NF, NFK, LFULL, CAUSAL, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((attn_mfma_kernel<T, NF, NFK>), dim3(1, p.H, p.B), dim3(256), lds, stream, p);
+  if (p.abl & 64) {                                    // development: how many blocks share a CU
+    int nb = 0; CC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(attn_mfma_kernel<T, NF, NFK, LFULL, CAUSAL, NQ>), 256, lds));
+    fprintf(stderr, "[clearcam] attn_mfma_kernel<NF=%d, NFK=%d, LFULL=%d>: %zu bytes of LDS, %d blocks per CU\n", NF, NFK, LFULL, lds, nb);
+  }
+  hipLaunchKernelGGL((attn_mfma_kernel<T, NF, NFK, LFULL, CAUSAL, NQ>), dim3(1, p.H, p.B), dim3(256), lds, stream, p);
 }
 template <class T> static void launch_attn_t(const AttnP& p, hipStream_t stream) {
-  // K keeps only the fragments that can hold a real key: 17 of 18 for 257 keys (two blocks per CU need <= 80 KB each)
+  // the shapes the reference runs get straight-line instantiations: ViT-L/14's 257 tokens, ViT-B/32's 50, the text tower's 77 causal ones
+  if (p.L == 257 && !p.causal) {                       // sixteen whole tiles = two pairs per wave + the split seventeenth
+    if (p.abl & 128) launch_attn_mfma<T, 18, 17, 16, 0, 1>(p, stream); else launch_attn_mfma<T, 18, 17, 16, 0, 2>(p, stream);
+    return;
+  }
+  if (p.L == 50 && !p.causal) { launch_attn_mfma<T, 6, 5, 3, 0>(p, stream); return; }
+  if (p.L == 77 && p.causal) { launch_attn_mfma<T, 6, 5, 4, 1>(p, stream); return; }
+  // any other length: K keeps only the fragments that can hold a real key (17 of 18 up to 272 keys: two blocks per CU need <= 80 KB each)
   if (p.L <= 80) launch_attn_mfma<T, 6, 5>(p, stream);
   else if (p.L <= 96) launch_attn_mfma<T, 6, 6>(p, stream);
   else if (p.L <= 272) launch_attn_mfma<T, 18, 17>(p, stream);

@@ -163,7 +163,8 @@ struct AttnP {                // softmax(q k^T / sqrt(dh)) v per head, dh = 64  
   const void* qkv;            // (B*L, 3*D) storage dtype: [q | k | v]
   void* ctx;                  // (B*L, D)
   int B, L, H, D; int causal; float scale;
-  int abl;                    // development (cc_attn_bench): 1 = stage K / V only, 2 = no staging (tiles over whatever LDS holds); 0 in production
+  int abl;                    // development (cc_attn_bench): 1 = stage K / V only, 2 = no staging (tiles over whatever LDS holds), 32 = empty blocks,
+                              // 64 = print the occupancy, 128 = one query tile per wave round instead of two; 0 in production
 };
 void launch_attention(int dt, const AttnP& p, hipStream_t stream);
 

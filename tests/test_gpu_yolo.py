@@ -538,6 +538,31 @@ def test_small_model_sizes_run(sd_t):
         assert n_match >= 0.99 * max(n_ref, n_got) - 1 and box_err <= 0.64 and sc_err <= 1e-3, (size, n_ref, n_got, n_match)
 
 
+@pytest.mark.parametrize("size,res", [("t", 320), ("s", 320), ("m", 320), ("e", 320)])
+def test_split_weight_mode_all_sizes(size, res):
+    """dtype "f16s" through every graph variant: ELAN1 / AConv (t, s), channel counts off the 16-byte grid -> the direct kernel (m), the
+    43-block graph with CBLinear / CBFuse (e).  The seeded checkpoints of these sizes are chaotic (perturbation gain 30-60x), so the check
+    is relative: split weights must not be further from the f32 oracle's P3..P5 than plain f16 (whose weights carry 11 bits), and the
+    run is finite, deterministic and batch-invariant."""
+    from clearcam_amd.weights import synthetic_yolov9_state_dict
+    sd = synthetic_yolov9_state_dict(size, 1234)
+    frames = noise_frames(7, 2, res, res)
+    o = yo.YOLOv9Oracle(size, res, sd)
+    with torch.no_grad():
+        feats = [f.permute(0, 2, 3, 1).numpy() for f in o.features(o.network_input(frames))]
+    rel = {}
+    for dt in ("f16s", "f16"):
+        m = _yolo(size, res, sd, dt)
+        got = m.detect_batch(frames)
+        assert np.isfinite(got).all()
+        rel[dt] = [float(np.sqrt(((m.get_tensor(n) - r) ** 2).mean() / (r ** 2).mean())) for n, r in zip(("p3", "p4", "p5"), feats)]
+        if dt == "f16s":
+            assert np.array_equal(got, m.detect_batch(frames)) and np.array_equal(got[1], m.detect_batch(frames[1:2])[0])
+        m.close()
+    print(size, rel)
+    assert all(a <= 1.1 * b + 1e-4 for a, b in zip(rel["f16s"], rel["f16"])), (size, rel)
+
+
 BIG_CASES = [
     ("big_1x1", 1, 512, 48, 48, 256, 1),                 # 9 m-tiles of 256 pixels, ragged last tile, 8 K steps
     ("big_1x1_k64", 2, 64, 16, 16, 512, 1),              # a single K step: prologue-only pipeline
