@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libclearcam_hip.so")
 SYMBOLS = [
     "cc_last_error", "cc_version", "cc_device_count",
     "cc_yolo_create", "cc_yolo_load", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_set_in_flight", "cc_yolo_submit", "cc_yolo_wait",
-    "cc_yolo_get_tensor",
+    "cc_yolo_get_tensor", "cc_yolo_nonfinite",
     "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_profile_graph", "cc_yolo_destroy", "cc_conv2d_nhwc", "cc_conv_bench", "cc_dev_set", "cc_round_weights_feedback", "cc_attn_bench",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
     "cc_clip_set_in_flight", "cc_clip_submit_image", "cc_clip_wait",
@@ -64,6 +64,7 @@ def lib() -> C.CDLL:
         "cc_yolo_submit": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_longlong)],
         "cc_yolo_wait": [vp, C.c_longlong, vp],
         "cc_yolo_get_tensor": [vp, C.c_char_p, vp, i64p, ip],
+        "cc_yolo_nonfinite": [vp, ip],
         "cc_yolo_last_gpu_ms": [vp, fp],
         "cc_yolo_profile": [vp, C.c_int, fp, C.POINTER(C.c_double), ip],
         "cc_yolo_profile_graph": [vp, C.c_int, C.c_int, fp],

@@ -407,6 +407,9 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
   o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3];
   o[4] = best >= p.conf ? best : 0.f;
   o[5] = (float)bi;
+  // every finite logit has a sigmoid above -1: `best` still at its initial value, or a box that is not a number, means the activations
+  // left the storage type's range somewhere upstream (f16 saturates at 65504) - counted, so that the caller is told instead of getting no detections
+  if (p.nonfinite && (!(best >= 0.f) || !(box[0] - box[0] == 0.f) || !(box[2] - box[2] == 0.f))) atomicAdd(p.nonfinite, 1);
 }
 
 // ---- DDetect tail: last 1x1 convs of both branches + decode, logits on chip ---------------------------------------------------
@@ -527,6 +530,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailP p, int b
       float* o = p.det + ((size_t)b * p.A + aoff + a) * 6;
       if (fg == 0) { o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3]; }
       else if (fg == 1) { o[4] = best >= p.conf ? best : 0.f; o[5] = (float)bi; }
+      if (p.nonfinite && ((fg == 1 && !(best >= 0.f)) || (fg == 0 && (!(box[0] - box[0] == 0.f) || !(box[2] - box[2] == 0.f))))) atomicAdd(p.nonfinite, 1);   // as decode_kernel
     }
     __builtin_amdgcn_wave_barrier();                    // the next tile overwrites this wave's logits
 #pragma unroll

@@ -95,6 +95,7 @@ struct DecodeP {              // DDetect decode + class max: detection/yolov9.py
   const float* dfl_w;                     // 16 weights
   float conf;                             // 0.25
   float* det;                             // (B,A,6) x1,y1,x2,y2,score(thresholded),cls
+  int* nonfinite;                         // device counter: anchors whose logits were not finite (f16 activations past 65504 -> inf -> NaN); may be null
 };
 void launch_decode(const DecodeP& p, hipStream_t stream);
 
@@ -112,6 +113,7 @@ struct HeadTailP {
   int B, A;
   const float* dfl_w; float conf;
   float* det;                             // (B,A,6)
+  int* nonfinite;                         // as DecodeP::nonfinite
 };
 bool head_tail_supported(int dt, int ch, int split = 0);
 void launch_head_tail(int dt, const HeadTailP& p, hipStream_t stream);

@@ -72,12 +72,13 @@ struct Plan {
   void* frames_dev = nullptr; size_t frames_bytes = 0;
   bool fused_stem = false; const void* last_frames = nullptr;   // no materialised network input; frames of the last detect call
   float* det = nullptr; float* out_dev = nullptr;
+  int* nonfinite = nullptr;                            // device counter of anchors with non-finite logits (decode / DDetect tail), summed over the plan's life
   hipGraphExec_t exec = nullptr;
   std::vector<hipEvent_t> lane_ev;                     // the cross-lane edges of the captured graph (run_ops_lanes)
   ~Plan() {
     if (exec) hipGraphExecDestroy(exec);
     for (hipEvent_t e : lane_ev) if (e) hipEventDestroy(e);
-    for (void* p : {(void*)arena, (void*)xlo, (void*)xhi, (void*)ylo, (void*)yhi, (void*)xfr, (void*)yfr, frames_dev, (void*)det, (void*)out_dev})
+    for (void* p : {(void*)arena, (void*)xlo, (void*)xhi, (void*)ylo, (void*)yhi, (void*)xfr, (void*)yfr, frames_dev, (void*)det, (void*)out_dev, (void*)nonfinite})
       if (p) hipFree(p);
   }
 };
@@ -99,6 +100,7 @@ struct cc_yolo {
   long long submitted = 0;
   hipStream_t stream_of_slot(int i) const { return i == 0 ? stream : slot_stream[i - 1]; }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int* nonfinite_host = nullptr;                       // pinned: the plan's counter lands here with the rows of a host-output call
   std::map<std::string, HostTensor> host;
   std::map<std::string, PackedConv> packed;
   float* dfl_w = nullptr;
@@ -753,6 +755,7 @@ struct Builder {
     CC_HIP(hipMemset(P->arena, 0, P->arena_bytes));
     CC_HIP(hipMalloc((void**)&P->det, (size_t)P->B * P->A * 6 * 4));
     CC_HIP(hipMalloc((void**)&P->out_dev, (size_t)P->B * CC_MAX_DET * 6 * 4));
+    CC_HIP(hipMalloc((void**)&P->nonfinite, 256)); CC_HIP(hipMemset(P->nonfinite, 0, 256));
     auto ptr = [&](const void* id) -> char* { const intptr_t i = (intptr_t)id; return i < 0 ? nullptr : P->arena + P->bufs[i].off; };
     for (Op& op : P->ops) {
       if (op.kind == 0) {
@@ -760,11 +763,11 @@ struct Builder {
         if (!op.conv.s1.ptr) op.conv.s1.ptr = op.conv.s0.ptr;
         op.conv.out = ptr(op.conv.out); op.conv.res = ptr(op.conv.res);
       } else if (op.kind == 1) { op.pool.in = ptr(op.pool.in); op.pool.out = ptr(op.pool.out); }
-      else if (op.kind == 2) { for (int l = 0; l < 3; ++l) op.dec.raw[l] = (const float*)ptr(op.dec.raw[l]); op.dec.det = P->det; }
+      else if (op.kind == 2) { for (int l = 0; l < 3; ++l) op.dec.raw[l] = (const float*)ptr(op.dec.raw[l]); op.dec.det = P->det; op.dec.nonfinite = P->nonfinite; }
       else if (op.kind == 4) { for (int k = 0; k < op.fuse.n; ++k) op.fuse.in[k] = ptr(op.fuse.in[k]); op.fuse.out = ptr(op.fuse.out); }
       else if (op.kind == 5) op.stem.out = ptr(op.stem.out);
       else if (op.kind == 6) { op.csp.x = ptr(op.csp.x); op.csp.out = ptr(op.csp.out); }
-      else if (op.kind == 7) { for (int l = 0; l < 3; ++l) { op.tail.bx[l] = ptr(op.tail.bx[l]); op.tail.cl[l] = ptr(op.tail.cl[l]); } op.tail.det = P->det; }
+      else if (op.kind == 7) { for (int l = 0; l < 3; ++l) { op.tail.bx[l] = ptr(op.tail.bx[l]); op.tail.cl[l] = ptr(op.tail.cl[l]); } op.tail.det = P->det; op.tail.nonfinite = P->nonfinite; }
       else { op.nms.det = P->det; op.nms.out = P->out_dev; }
     }
   }
@@ -1035,6 +1038,7 @@ int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device
   y->arch = a; y->res = res; y->dtype = storage_dtype(dtype); y->wsplit = dtype == F16S; y->device = device;
   y->stream = pool_stream_get(device);
   CC_HIP(hipEventCreate(&y->ev0)); CC_HIP(hipEventCreate(&y->ev1));
+  CC_HIP(hipHostMalloc((void**)&y->nonfinite_host, 64, hipHostMallocDefault)); *y->nonfinite_host = 0;
   *h = y.release();
   CC_API_END
 }
@@ -1118,7 +1122,15 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
     }
   } else {
     CC_HIP(hipMemcpyAsync(out, P->out_dev, ob, hipMemcpyDeviceToHost, s));
+    CC_HIP(hipMemcpyAsync(h->nonfinite_host, P->nonfinite, 4, hipMemcpyDeviceToHost, s));
     CC_HIP(hipStreamSynchronize(s));
+    h->last = P;
+    if (*h->nonfinite_host) {                               // the rows are in `out` (garbage where the logits were); say why
+      const int n = *h->nonfinite_host;
+      *h->nonfinite_host = 0; CC_HIP(hipMemsetAsync(P->nonfinite, 0, 4, s));
+      throw cc::Error(-34, std::to_string(n) + " anchors with non-finite logits: activations left the storage type's range (f16 saturates at 65504) - "
+                           "run this checkpoint with dtype bf16 or f32");
+    }
   }
   h->last = P;
   CC_API_END
@@ -1227,6 +1239,21 @@ int cc_yolo_get_tensor(cc_yolo* h, const char* name, float* out, int64_t* shape,
       else v = bf16_bits_to_f32(((const uint16_t*)tmp.data())[j]);
       out[i * C + c] = v;
     }
+  CC_API_END
+}
+
+int cc_yolo_nonfinite(cc_yolo* h, int* count) {
+  CC_API_BEGIN
+  CC_CHECK(h && count, "null argument");
+  CC_HIP(hipSetDevice(h->device));
+  sync_all(h);
+  int total = 0;
+  for (auto& kv : h->plans.slots) {
+    int n = 0; CC_HIP(hipMemcpy(&n, kv.second.plan->nonfinite, 4, hipMemcpyDeviceToHost));
+    if (n) CC_HIP(hipMemset(kv.second.plan->nonfinite, 0, 4));
+    total += n;
+  }
+  *count = total;
   CC_API_END
 }
 
@@ -1349,6 +1376,7 @@ void cc_yolo_destroy(cc_yolo* h) {
   if (h->dfl_w) hipFree(h->dfl_w);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->nonfinite_host) hipHostFree(h->nonfinite_host);
   for (hipStream_t t : h->side) pool_stream_put(h->device, t);              // parked, never destroyed (kernels.h)
   for (hipStream_t t : h->slot_stream) pool_stream_put(h->device, t);
   for (hipEvent_t e : h->slot_done) hipEventDestroy(e);

@@ -144,6 +144,13 @@ class YOLOv9:
         _lib.check(L.cc_yolo_get_tensor(self._h, name.encode(), _lib.ptr(out), shp, C.byref(nd)))
         return out
 
+    def nonfinite(self) -> int:
+        """Anchors whose logits were not finite since the last query (f16 activations past 65504): non-zero means this checkpoint needs
+        dtype "bf16" or "f32".  Host-output calls (detect_batch, __call__) raise by themselves; device-output / submit() calls do not."""
+        n = C.c_int()
+        _lib.check(_lib.lib().cc_yolo_nonfinite(self._h, C.byref(n)))
+        return n.value
+
     def last_gpu_ms(self) -> float:
         ms = C.c_float()
         _lib.check(_lib.lib().cc_yolo_last_gpu_ms(self._h, C.byref(ms)))

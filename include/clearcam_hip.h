@@ -51,6 +51,12 @@ int cc_yolo_finalize(cc_yolo* h);
  * B=1 is exactly the reference call.  frames_on_device/out_on_device select host or device pointers. */
 int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int frame_f32,
                    int frames_on_device, float* out, int out_on_device, void* stream);
+/* Range guard of the 16-bit modes: f16 activations saturate at 65504, and a checkpoint that drives them past it yields inf -> NaN logits,
+ * which every threshold silently turns into "no detection".  The decode stage counts anchors whose logits were not finite: a
+ * cc_yolo_detect call that returns its rows to HOST memory fails with -34 (ERANGE) and a message naming the remedy (dtype bf16 / f32) when
+ * the count is non-zero; for device-output and cc_yolo_submit calls cc_yolo_nonfinite waits for the handle's streams and returns (and
+ * clears) the count accumulated since the last query. */
+int cc_yolo_nonfinite(cc_yolo* h, int* count);
 /* Batches in flight - throughput mode for a GPU that serves many cameras (no counterpart in the reference, whose loop is one
  * synchronous batch-1 call per frame, clearcam.py:583).  cc_yolo_set_in_flight(h, n) gives the handle n slots (1..8, default 1), each
  * with its own stream, tensor arena and captured graph (the streams are probed until kernels on them really run side by side);

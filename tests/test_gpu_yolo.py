@@ -493,6 +493,32 @@ def test_batch_invariance_and_determinism(sd_c, dtype):
     assert (a[dead][:, :4].max() if dead.any() else 0) <= 640
 
 
+def test_f16_range_overflow_is_reported(sd_t):
+    """f16 activations saturate at 65504; past it they become inf -> NaN logits, which every threshold silently turns into "no detection".
+    A checkpoint that does this must be REPORTED: host-output calls fail with a message naming the remedy, device-output calls leave a
+    count behind (cc_yolo_nonfinite); bf16 / f32 storage run the same checkpoint fine."""
+    from clearcam_amd._lib import CCError
+    sd = {k: np.array(v, copy=True) for k, v in sd_t.items()}
+    sd["model.list.0.conv.weight"] = sd["model.list.0.conv.weight"] * np.float32(3e5)       # first conv's outputs far beyond 65504
+    frames = noise_frames(3, 2, 320, 320)
+    for dt in ("f16", "f16s"):
+        m = _yolo("t", 320, sd, dt)
+        with pytest.raises(CCError, match="non-finite"):
+            m.detect_batch(frames)
+        out = torch.empty(2, 300, 6, device="cuda")
+        m.detect_batch_device(torch.from_numpy(frames).cuda(), out)
+        torch.cuda.synchronize()
+        assert m.nonfinite() > 0 and m.nonfinite() == 0                                      # reported once, then cleared
+        m.close()
+    for dt in ("bf16", "f32"):
+        m = _yolo("t", 320, sd, dt)
+        assert np.isfinite(m.detect_batch(frames)).all() and m.nonfinite() == 0
+        m.close()
+    ok = _yolo("t", 320, sd_t, "f16")                                                         # the unmodified checkpoint: nothing to report
+    ok.detect_batch(frames)
+    assert ok.nonfinite() == 0
+
+
 def test_reference_call_surface(sd_t):
     """clearcam.py:582-583 / run_mot.py:33-34 call shapes, through the shims."""
     from clearcam_amd.helpers import Tensor, jit_infer
