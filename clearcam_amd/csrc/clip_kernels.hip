@@ -30,36 +30,66 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- LayerNorm: one wave per row, D <= 1024 ------------------------------------------------------
-template <class T>
+// VEC: D is a multiple of 4 and the rows are 16-byte aligned - the lane owns four float4 groups, 256 elements apart: every load is one
+// 1 KB line-contiguous wave access (4 instead of 16 load instructions per row), gamma / beta likewise, and the row leaves as 8-byte
+// (16-bit storage) or 16-byte stores instead of sixteen 2-byte ones.  Same arithmetic per element, same reduction order across the lanes'
+// partial sums is NOT the same as the scalar form's (lane l sums elements 4l.., not l + 64 i) - an f32 rounding-level difference.
+template <class T, bool VEC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= p.rows) return;
   const float* x = p.in + (long)(p.row_index ? p.row_index[row] : row) * p.in_row_stride;
   float v[16];
   float s = 0.f;
+  if constexpr (VEC) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { const int j = lane + 64 * i; v[i] = j < p.D ? x[j] : 0.f; s += v[i]; }
+    for (int i = 0; i < 4; ++i) {
+      const int j = (lane + 64 * i) * 4;
+      const float4 t = j < p.D ? *reinterpret_cast<const float4*>(x + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+      s += (t.x + t.y) + (t.z + t.w);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int j = lane + 64 * i; v[i] = j < p.D ? x[j] : 0.f; s += v[i]; }
+  }
   const float mean = wave_sum(s) / (float)p.D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { const int j = lane + 64 * i; const float d = j < p.D ? v[i] - mean : 0.f; q += d * d; }
+  for (int i = 0; i < 16; ++i) { const int j = VEC ? (lane + 64 * (i >> 2)) * 4 + (i & 3) : lane + 64 * i; const float d = j < p.D ? v[i] - mean : 0.f; q += d * d; }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.D + 1e-5f);
+  if constexpr (VEC) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int j = lane + 64 * i;
-    if (j < p.D) {
-      const float y = (v[i] - mean) * rstd * p.w[j] + p.b[j];
-      if (p.out_f32) reinterpret_cast<float*>(p.out)[(size_t)row * p.D + j] = y;
-      else reinterpret_cast<T*>(p.out)[(size_t)row * p.D + j] = from_f32<T>(y);
+    for (int i = 0; i < 4; ++i) {
+      const int j = (lane + 64 * i) * 4;
+      if (j < p.D) {
+        const float4 w4 = *reinterpret_cast<const float4*>(p.w + j), b4 = *reinterpret_cast<const float4*>(p.b + j);
+        const float y0 = (v[4 * i] - mean) * rstd * w4.x + b4.x, y1 = (v[4 * i + 1] - mean) * rstd * w4.y + b4.y;
+        const float y2 = (v[4 * i + 2] - mean) * rstd * w4.z + b4.z, y3 = (v[4 * i + 3] - mean) * rstd * w4.w + b4.w;
+        if (p.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)row * p.D + j) = make_float4(y0, y1, y2, y3);
+        else if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.out) + (size_t)row * p.D + j) = make_uint2(pack2<T>(y0, y1), pack2<T>(y2, y3));
+        else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)row * p.D + j) = make_float4(y0, y1, y2, y3);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = lane + 64 * i;
+      if (j < p.D) {
+        const float y = (v[i] - mean) * rstd * p.w[j] + p.b[j];
+        if (p.out_f32) reinterpret_cast<float*>(p.out)[(size_t)row * p.D + j] = y;
+        else reinterpret_cast<T*>(p.out)[(size_t)row * p.D + j] = from_f32<T>(y);
+      }
     }
   }
 }
 void launch_layernorm(int dt, const LnP& p, hipStream_t stream) {
   CC_CHECK(p.D <= 1024, "layernorm: D > 1024");
   const dim3 grid((p.rows + 3) / 4), block(256);
-  if (dt == F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, stream, p);
-  else if (dt == F16) hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, block, 0, stream, p);
-  else hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, stream, p);
+  const bool vec = p.D % 4 == 0 && p.in_row_stride % 4 == 0 && (((uintptr_t)p.in | (uintptr_t)p.out | (uintptr_t)p.w | (uintptr_t)p.b) & 15) == 0;
+  if (dt == F32) { if (vec) hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, stream, p); }
+  else if (dt == F16) { if (vec) hipLaunchKernelGGL((layernorm_kernel<f16_t, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((layernorm_kernel<f16_t, false>), grid, block, 0, stream, p); }
+  else { if (vec) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, stream, p); }
   CC_HIP(hipGetLastError());
 }
 
