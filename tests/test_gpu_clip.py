@@ -226,6 +226,28 @@ def test_clip_b32_matches_oracle(dtype):
         assert np.abs(ref - got).max() < 1e-5
 
 
+@pytest.mark.parametrize("image_size,patch,t_ctx", [(112, 14, 40),      # 65 image tokens: five query tiles, the last one split over the keys; 40 causal text tokens
+                                                   (224, 16, 65),      # 197 tokens (ViT-B/16's count): thirteen tiles + split tail on the 18-fragment instantiation; 65 causal
+                                                   (168, 14, 96),      # 145 tokens: ten tiles, no split; 96 text tokens = six whole key fragments
+                                                   (224, 14, 77)])     # 257 / 77: the straight-line instantiations, next to the run-time form on the same weights' shapes
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_attention_token_counts(dtype, image_size, patch, t_ctx):
+    """attn_mfma_kernel beyond the three token counts the reference runs: other lengths take the run-time form of the score / softmax section
+    (key-padding and causal masks decided per fragment at run time), with and without the split last query tile - against the oracle."""
+    from dataclasses import replace
+    from clearcam_amd.objects import OpenCLIP
+    arch = replace(CLIP_TINY, image_size=image_size, patch=patch, t_ctx=t_ctx, v_width=128, v_heads=2, t_width=64, t_heads=1)
+    sd = synthetic_clip_state_dict(arch, 17)
+    o = OpenCLIPOracle(sd, arch)
+    m = OpenCLIP(state_dict=sd, arch=arch, dtype=dtype)
+    x = np.random.default_rng(5).random((3, 3, image_size, image_size), dtype=np.float32) * 2 - 1
+    ref, got = o.precompute_embedding(x), m.precompute_embedding(x).numpy()
+    assert ((ref * got).sum(1) >= 1 - 1e-4).all(), (ref * got).sum(1)
+    sot, eot = arch.t_vocab - 2, arch.t_vocab - 1
+    toks = np.concatenate([pad_tokens([5, 9, 44], t_ctx, sot, eot), pad_tokens(list(range(1, t_ctx - 1)), t_ctx, sot, eot), pad_tokens([], t_ctx, sot, eot)])
+    assert ((o.encode_tokens(toks) * m.encode_tokens(toks)).sum(1) >= 1 - 1e-4).all()
+
+
 def test_multi_query_scan_matches_single_query_path():
     """Q > 4 queries go through one GEMM pass over the index (exact-f32 MFMA) instead of ceil(Q/4) GEMV passes: same
     scores to f32 rounding, same top-k semantics (stable descending order of the returned scores)."""
