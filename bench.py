@@ -179,8 +179,8 @@ def measured_parity(device_index: int, n_cond: int = 16, n_chaotic: int = 4) -> 
                     s["match_frac_clear_of_threshold"] >= 0.985 and s["match_frac"] >= 0.975)
     out["holds_tolerance_with_unrounded_weights"] = {dt: holds(out["weights_unrounded"][dt]) for dt in ("f16s", "f16", "bf16")}
     out["holds_tolerance_note"] = ("per-anchor box error <= 0.64 px for every anchor, scores within 2e-3, >= 98.5 % strict matches clear of the threshold, against the "
-                                   "f32 oracle on the conditioned checkpoint with its float32 weights NOT pre-rounded; f16 / bf16 round their weights with error feedback "
-                                   "(yolo.hip round_with_feedback), f16s carries them as two f16 planes")
+                                   "f32 oracle on the conditioned checkpoint with its float32 weights NOT pre-rounded; f16 / bf16 round their weights with controlled rounding "
+                                   "(yolo.hip round_controlled: filter sums preserved), f16s carries them as two f16 planes")
     return out
 
 

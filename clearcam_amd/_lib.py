@@ -12,7 +12,7 @@ SYMBOLS = [
     "cc_last_error", "cc_version", "cc_device_count",
     "cc_yolo_create", "cc_yolo_load", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_set_in_flight", "cc_yolo_submit", "cc_yolo_wait",
     "cc_yolo_get_tensor", "cc_yolo_nonfinite",
-    "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_profile_graph", "cc_yolo_destroy", "cc_conv2d_nhwc", "cc_conv_bench", "cc_dev_set", "cc_round_weights_feedback", "cc_attn_bench",
+    "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_profile_graph", "cc_yolo_destroy", "cc_conv2d_nhwc", "cc_conv_bench", "cc_dev_set", "cc_round_weights", "cc_attn_bench",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
     "cc_clip_set_in_flight", "cc_clip_submit_image", "cc_clip_wait",
     "cc_clip_last_gpu_ms", "cc_clip_destroy", "cc_crop_preprocess", "cc_cv_resize_linear_u8", "cc_cv_warp_affine_u8",
@@ -72,7 +72,7 @@ def lib() -> C.CDLL:
                            C.c_int, vp, C.c_int, vp],
         "cc_conv_bench": [C.c_int] * 11 + [fp],
         "cc_dev_set": [C.c_char_p, C.c_int],
-        "cc_round_weights_feedback": [C.c_int, vp, C.c_int64, C.c_int64, vp],
+        "cc_round_weights": [C.c_int, vp, C.c_int64, C.c_int64, C.c_int64, vp],
         "cc_attn_bench": [C.c_int] * 7 + [fp],
         "cc_clip_create": [C.POINTER(vp), C.POINTER(ClipConfig), C.c_int, C.c_int],
         "cc_clip_load": [vp, C.c_char_p, vp, i64p, C.c_int],

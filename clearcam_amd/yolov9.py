@@ -31,7 +31,7 @@ class YOLOv9:
                  weights: Optional[str] = None, dtype: str = "f16s", device: int = 0):
         """dtype: "f16s" (default) - f16 activations, split f16 weights: detections within the reference tolerance for any float32
         checkpoint; "f32" - the exact-arithmetic parity mode (5x slower than f16s); "f16" / "bf16" - speed modes whose 11 / 8-bit weight
-        rounding (error-feedback rounded) moves boxes by up to a pixel / several pixels on the conditioned synthetic checkpoint.  f16
+        rounding (controlled rounding: filter sums preserved) moves boxes by up to a pixel / several pixels on the conditioned synthetic checkpoint.  f16
         storage saturates at 65504: a checkpoint whose activations exceed that needs "bf16" or "f32"."""
         if size not in YOLO_ARCH and size != "e":
             raise ValueError(f"unsupported size {size!r}: t, s, m, c, e")

@@ -106,11 +106,11 @@ int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int 
 /* Diagnostic (kernel tuning, tools/dev/attn_ab.py): average device milliseconds of one attention launch (B images, L tokens, H heads of 64)
  * on random 16-bit data; abl: 0 the kernel, 1 K / V staging only, 2 tiles without staging.  Not part of the drop-in surface. */
 int cc_attn_bench(int dtype, int B, int L, int H, int causal, int abl, int iters, float* ms);
-/* Host-only helper (no GPU needed; tests / tooling): the error-feedback rounding cc_yolo_finalize applies to a conv's OIHW float32
- * weights for the plain 16-bit storage types (dtype 1 / 2) - along each of the `cout` output channels (`per_channel` = Cin*kh*kw
- * weights each) the rounding residual of a weight is added to the next one before it is rounded.  out[i] = the value the storage
- * type holds, as float32. */
-int cc_round_weights_feedback(int dtype, const float* w, int64_t cout, int64_t per_channel, float* out);
+/* Host-only helper (no GPU needed; tests / tooling): the CONTROLLED rounding cc_yolo_finalize applies to a conv's OIHW float32 weights
+ * (cout, cin, k, k) for the plain 16-bit storage types (dtype 1 / 2): every weight goes to one of its two neighbours in the storage
+ * type, chosen so that each output channel's total, the tap-sums of each input channel's filter, the channel-sums at each tap and the
+ * first moments over the taps stay within about an ulp of their float32 values.  out[i] = the value the storage type holds, as float32. */
+int cc_round_weights(int dtype, const float* w, int64_t cout, int64_t cin, int64_t k, float* out);
 /* Diagnostic (kernel tuning): set a process-wide tuning switch at run time so that one process can A/B kernel variants.
  * key "phase_flags": the CLEARCAM_PHASE_FLAGS bit set of the eight-wave kernel (-1 = back to the environment / default).
  * Plans already built keep the launches they were built with.  Not part of the drop-in surface. */

@@ -6,9 +6,10 @@
 add) runs in f32 and the result is rounded ONCE when it is written (clearcam_amd/csrc/conv_mfma.hip
 ``conv_epilogue``).  This class applies exactly those roundings to the oracle:
 
-  * every conv weight            -> storage type (bias stays f32); ``feedback=True`` (the library's default, yolo.hip
-                                    ``round_with_feedback``) rounds along each output channel with error feedback: the residual
-                                    of one weight is added to the next before it is rounded
+  * every conv weight            -> storage type (bias stays f32); ``feedback=True`` = the library's default rounding (yolo.hip
+                                    ``round_controlled``): each weight goes to one of its two neighbours in the storage type so
+                                    that the output channel's total, each input channel's tap-sum and each tap's channel-sum of
+                                    the rounding residuals stay near zero
   * the network input  x/255     -> storage type (detect.hip ``stem_fused_kernel`` / ``preprocess_kernel``)
   * every ``Conv`` output        -> storage type after SiLU; a RepNBottleneck's ``x + cv2(cv1(x))``
                                     (detection/yolov9.py:89) is rounded once after the add
@@ -44,15 +45,54 @@ class LowPrecOracle(YOLOv9Oracle):
                 self.sd[k] = self.q_feedback(self.sd[k]) if feedback else self.q(self.sd[k])
 
     def q_feedback(self, w: torch.Tensor) -> torch.Tensor:
-        """clearcam_amd/csrc/yolo.hip ``round_with_feedback``: float32 arithmetic, OIHW order within an output channel."""
-        co = w.shape[0]
-        flat = w.reshape(co, -1).to(torch.float32)
-        q = torch.empty_like(flat)
-        e = torch.zeros(co, dtype=torch.float32)
-        for k in range(flat.shape[1]):
-            t = flat[:, k] + e
-            q[:, k] = self.q(t)
-            e = t - q[:, k]
+        """clearcam_amd/csrc/yolo.hip ``round_controlled``: the same float32 operations in the same order (two passes per output channel)."""
+        co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+        taps = k * k
+        wf = w.reshape(co, ci, taps).to(torch.float32)
+        r = self.q(wf)
+        inf = torch.tensor(float("inf"), dtype=self.t)
+        lo = torch.where(r > wf, torch.nextafter(r.to(self.t), -inf).to(torch.float32), r)
+        hi = torch.where(r < wf, torch.nextafter(r.to(self.t), inf).to(torch.float32), r)
+        rr = [float(t // k) - (k - 1) / 2.0 for t in range(taps)]
+        ss = [float(t % k) - (k - 1) / 2.0 for t in range(taps)]
+        mom = taps > 1
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32)      # noqa: E731
+        q, d = torch.empty_like(wf), torch.empty_like(wf)
+        e_row, e_col, e_tot, m_r, m_s = z(co, ci), z(co, taps), z(co), z(co), z(co)
+
+        def cost(er, ec, dd, t):
+            v = (er + dd) * (er + dd) + (ec + dd) * (ec + dd) + 2.0 * ((e_tot + dd) * (e_tot + dd))
+            if mom:
+                v = v + ((m_r + dd * rr[t]) * (m_r + dd * rr[t]) + (m_s + dd * ss[t]) * (m_s + dd * ss[t]))
+            return v
+
+        for c in range(ci):                                      # pass 1: sequential, running sums
+            er = z(co)
+            for t in range(taps):
+                dl, dh = lo[:, c, t] - wf[:, c, t], hi[:, c, t] - wf[:, c, t]
+                up = cost(er, e_col[:, t], dh, t) < cost(er, e_col[:, t], dl, t)
+                dd = torch.where(up, dh, dl)
+                q[:, c, t] = torch.where(up, hi[:, c, t], lo[:, c, t])
+                d[:, c, t] = dd
+                er = er + dd
+                e_col[:, t] = e_col[:, t] + dd
+                e_tot = e_tot + dd
+                if mom:
+                    m_r, m_s = m_r + dd * rr[t], m_s + dd * ss[t]
+            e_row[:, c] = er
+        for c in range(ci):                                      # pass 2: every weight again, all others fixed
+            for t in range(taps):
+                dcur = d[:, c, t].clone()
+                dl, dh = (lo[:, c, t] - wf[:, c, t]) - dcur, (hi[:, c, t] - wf[:, c, t]) - dcur
+                up = cost(e_row[:, c], e_col[:, t], dh, t) < cost(e_row[:, c], e_col[:, t], dl, t)
+                de = torch.where(up, dh, dl)
+                q[:, c, t] = torch.where(up, hi[:, c, t], lo[:, c, t])
+                d[:, c, t] = dcur + de
+                e_row[:, c] = e_row[:, c] + de
+                e_col[:, t] = e_col[:, t] + de
+                e_tot = e_tot + de
+                if mom:
+                    m_r, m_s = m_r + de * rr[t], m_s + de * ss[t]
         return q.reshape(w.shape)
 
     def q(self, x: torch.Tensor) -> torch.Tensor:

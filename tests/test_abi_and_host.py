@@ -83,32 +83,40 @@ def test_synthetic_weights_are_deterministic(sd_t):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_error_feedback_weight_rounding_host(lib_path, dtype):
-    """cc_round_weights_feedback (the rounding cc_yolo_finalize applies to conv weights in the plain 16-bit modes; host code, no GPU):
-    bit-identical to the emulation in oracle/lowprec_oracle.py, every value representable in the storage type, every RUNNING sum of an
-    output channel's weights within half a unit in the last place of the float32 running sum (round-to-nearest lets it random-walk),
-    and values the type already holds exactly are left alone."""
+def test_controlled_weight_rounding_host(lib_path, dtype):
+    """cc_round_weights (the rounding cc_yolo_finalize applies to conv weights in the plain 16-bit modes; host code, no GPU):
+    bit-identical to the emulation in oracle/lowprec_oracle.py; every value is the weight's lower or upper neighbour in the storage type;
+    the output channel's total, every input channel's tap-sum and every tap's channel-sum of the rounded weights stay within ~two ulps of the
+    float32 sums (round-to-nearest lets them random-walk); values the type already holds exactly are left alone."""
     import torch
     from oracle.lowprec_oracle import LowPrecOracle
     L = _lib.lib()
     t = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    code = {"f16": 1, "bf16": 2}[dtype]
     g = torch.Generator().manual_seed(5)
     w = torch.randn(48, 32, 3, 3, generator=g) * 0.05
     out = np.empty(w.numel(), np.float32)
     wn = np.ascontiguousarray(w.numpy())
-    _lib.check(L.cc_round_weights_feedback({"f16": 1, "bf16": 2}[dtype], _lib.ptr(wn), 48, 32 * 9, _lib.ptr(out)))
+    _lib.check(L.cc_round_weights(code, _lib.ptr(wn), 48, 32, 3, _lib.ptr(out)))
     got = torch.from_numpy(out).reshape(w.shape)
     emu = LowPrecOracle.__new__(LowPrecOracle)
     emu.t = t
     assert torch.equal(got, emu.q_feedback(w))                                  # library == emulation, bit for bit
     assert torch.equal(got, got.to(t).float())                                  # representable
-    run_w = w.reshape(48, -1).double().cumsum(1)
-    run_fb = got.reshape(48, -1).double().cumsum(1)
-    run_nr = w.to(t).float().reshape(48, -1).double().cumsum(1)
+    near = w.to(t).float()
     ulp = 2.0 ** (np.floor(np.log2(float(w.abs().max()))) - (10 if dtype == "f16" else 7))
-    assert float((run_fb - run_w).abs().max()) <= 0.51 * ulp                    # the residual carried along never exceeds half an ulp
-    assert float((run_nr - run_w).abs().max()) > 2 * float((run_fb - run_w).abs().max())   # nearest rounding drifts
-    exact = w.to(t).float()
-    _lib.check(L.cc_round_weights_feedback({"f16": 1, "bf16": 2}[dtype], _lib.ptr(np.ascontiguousarray(exact.numpy())), 48, 32 * 9, _lib.ptr(out)))
+    assert float((got - w).abs().max()) <= 1.001 * ulp                          # a neighbour, never further
+    for name, dims in (("total", (1, 2, 3)), ("per input channel", (2, 3)), ("per tap", (1,))):
+        err_c = (got.double().sum(dims) - w.double().sum(dims)).abs().max()
+        err_n = (near.double().sum(dims) - w.double().sum(dims)).abs().max()
+        assert float(err_c) <= 2.0 * ulp, (name, float(err_c), ulp)             # the margins are preserved ...
+        if name != "per input channel":
+            assert float(err_n) > 2 * float(err_c), (name, float(err_n), float(err_c))   # ... where nearest rounding drifts (sqrt(n) ulps)
+    exact = near
+    _lib.check(L.cc_round_weights(code, _lib.ptr(np.ascontiguousarray(exact.numpy())), 48, 32, 3, _lib.ptr(out)))
     assert np.array_equal(out.reshape(w.shape), exact.numpy())
-    assert L.cc_round_weights_feedback(0, _lib.ptr(wn), 48, 288, _lib.ptr(out)) != 0       # f32 storage has nothing to round
+    w1 = torch.randn(16, 40, 1, 1, generator=g)                                 # 1x1: one tap, the table has a single column
+    o1 = np.empty(w1.numel(), np.float32)
+    _lib.check(L.cc_round_weights(code, _lib.ptr(np.ascontiguousarray(w1.numpy())), 16, 40, 1, _lib.ptr(o1)))
+    assert torch.equal(torch.from_numpy(o1).reshape(w1.shape), emu.q_feedback(w1))
+    assert L.cc_round_weights(0, _lib.ptr(wn), 48, 32, 3, _lib.ptr(out)) != 0   # f32 storage has nothing to round

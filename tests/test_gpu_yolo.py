@@ -343,7 +343,7 @@ def conditioned_case(frames, chunk=8, exact=True, emulate=()):
         from oracle.lowprec_oracle import LowPrecOracle
         emu = {}
         for dt in emulate:
-            lo = LowPrecOracle("c", res, sd, dt, feedback=True)           # the library rounds weights with error feedback (yolo.hip round_with_feedback)
+            lo = LowPrecOracle("c", res, sd, dt, feedback=True)           # the library's controlled weight rounding (yolo.hip round_controlled)
             d2, c2 = [], []
             with torch.no_grad():
                 for i in range(0, len(frames), chunk):
@@ -401,8 +401,10 @@ def test_detect_16bit_modes_match_oracle_at_bench_config(dtype):
 def test_detect_16bit_modes_with_unrounded_weights(dtype):
     """The same network with its float32 weights NOT pre-rounded to 16-bit-exact values: the speed mode's own rounding of the
     weights is inside the comparison.  Two references: (1) the storage-rounding emulation (what a correct 16-bit implementation
-    produces, f32 accumulation in another order): tight; (2) the f32 oracle: on this low-pass synthetic network weight rounding is
-    the dominant term (emulation: f16 97 % IoU matches, per-anchor p50 0.15 px; bf16 84 %, p50 1.0 px), the bars say so."""
+    produces - same controlled weight rounding, f32 accumulation in another order): tight; (2) the f32 oracle: with controlled rounding
+    (yolo.hip round_controlled) f16 comes close to the f32 gate's bars - 98.8 % strict matches, per-anchor p99 0.37 px, scores within 2e-3
+    over 48 frames in the CPU emulation, where round-to-nearest weights gave 92 % / 1.26 px - but not for EVERY anchor (max ~0.95 px):
+    the bars below say so; the mode that holds the 0.64 px bar for every anchor is f16s (next test)."""
     frames = noise_frames(1, 16, 640, 640)
     sd, ref, feats, dec_ref, emu = conditioned_case(frames, exact=False, emulate=(dtype,))
     m = _yolo("c", 640, sd, dtype)
@@ -410,15 +412,15 @@ def test_detect_16bit_modes_with_unrounded_weights(dtype):
     dec = m.get_tensor("decoded")
     tol = 1e-3 * 640
     vs_emu = yo.parity_summary(emu[dtype][0], got, tol, emu[dtype][1], dec)
-    vs_f32 = yo.parity_summary(ref, got, tol, dec_ref, dec)
+    vs_f32 = yo.parity_summary(ref, got, tol, dec_ref, dec, score_margin=2e-3)
     print(f"{dtype} un-rounded weights: vs emulation {vs_emu}\n  vs f32 oracle {vs_f32}")
     assert vs_emu["n_ref"] >= 100
     if dtype == "f16":
-        assert vs_emu["match_frac"] >= 0.97 and vs_emu["anchor_box_err_px_p99"] <= tol, vs_emu                   # measured 98.6 % (213 detections: 3 flips), p99 0.25 px
-        assert vs_f32["match_frac_iou_only"] >= 0.93 and vs_f32["anchor_box_err_px_p50"] <= tol, vs_f32
+        assert vs_emu["match_frac"] >= 0.97 and vs_emu["anchor_box_err_px_p99"] <= tol, vs_emu
+        assert vs_f32["match_frac_clear_of_threshold"] >= 0.97 and vs_f32["anchor_box_err_px_p99"] <= tol and vs_f32["anchor_score_err_max"] <= 3e-3, vs_f32
     else:
         assert vs_emu["match_frac_iou_only"] >= 0.93 and vs_emu["anchor_box_err_px_p50"] <= tol, vs_emu
-        assert vs_f32["match_frac_iou_only"] >= 0.70, vs_f32
+        assert vs_f32["match_frac_iou_only"] >= 0.85 and vs_f32["anchor_box_err_px_p50"] <= tol, vs_f32
 
 
 def test_detect_split_weight_mode_with_unrounded_weights():

@@ -1,7 +1,7 @@
 """Development probe (CPU): does f16 storage with SPLIT weights (W = W_hi + W_lo, two f16 planes, power-of-two layer scale) meet the
 f32 gate's yardstick on the conditioned checkpoint with UN-ROUNDED weights?
 
-    python tools/dev/split_eval.py [frames]
+    python tools/dev/split_eval.py [frames] [controlled]
 
 Emulates the storage roundings with oracle/lowprec_oracle.py; the weights are replaced by the 22-bit values the two planes hold.
 """
@@ -61,31 +61,8 @@ if __name__ == "__main__":
     print("seconds", round(time.time() - t0, 1))
 
 
-def feedback_f16(w: torch.Tensor) -> torch.Tensor:
-    """Plain f16 weights with ERROR-FEEDBACK rounding along each output channel's K walk (cin-major, then the 3x3 taps): the rounding
-    residual of one weight is added to the next before it is rounded, so that the filter sums (the DC gains) stay exact to half an ulp."""
-    co = w.shape[0]
-    flat = w.reshape(co, -1).double().clone()
-    q = torch.empty_like(flat)
-    e = torch.zeros(co, dtype=torch.float64)
-    for k in range(flat.shape[1]):
-        t = flat[:, k] + e
-        qk = t.to(torch.float16).double()
-        q[:, k] = qk
-        e = t - qk
-    return q.float().reshape(w.shape)
-
-
-class FeedbackOracle(LowPrecOracle):
-    def __init__(self, size, res, sd):
-        yo.YOLOv9Oracle.__init__(self, size, res, sd)
-        self.t = torch.float16
-        for k in list(self.sd):
-            if k.endswith(".weight") and self.sd[k].ndim == 4 and "dfl" not in k:
-                self.sd[k] = feedback_f16(self.sd[k])
-
-
-if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "feedback":
-    got, dec = run(FeedbackOracle("c", 640, sd), frames)
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "controlled":
+    # plain f16 storage with the library's controlled weight rounding (yolo.hip round_controlled = LowPrecOracle(feedback=True))
+    got, dec = run(LowPrecOracle("c", 640, sd, "f16", feedback=True), frames)
     s = yo.parity_summary(ref, got, 0.64, dec_ref, dec, score_margin=2e-3)
-    print("feedback", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items()}, flush=True)
+    print("controlled", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items()}, flush=True)
