@@ -91,6 +91,8 @@ struct cc_yolo {
   const Arch* arch = nullptr;
   int res = 640, dtype = BF16, device = 0;              // dtype: STORAGE type of activations and weights
   int wsplit = 0;                                      // C-ABI dtype 3 ("f16s"): f16 storage, every conv weight as two f16 planes (ConvP::split)
+  int split_rest_k = 0;                                // development: past split_last, convs of this filter size keep the low plane too
+  int split_last = 1 << 30;                            // ... up to this block of the graph (dtype 4, "f16h": 9 - the backbone; later blocks carry one plane)
   hipStream_t stream = nullptr;
   std::vector<hipStream_t> side;                       // streams of lanes 1.. while a plan is captured (run_ops_lanes)
   // Batches in flight (cc_yolo_submit / cc_yolo_wait): slot i > 0 has its own stream and its own plans (arena, graph), so the tail of
@@ -326,6 +328,11 @@ struct Builder {
   View whole(int buf) { return View{buf, 0, P->bufs[buf].C}; }
   static View slice(View v, int c0, int C) { return View{v.buf, v.coff + c0, C}; }
 
+  static int block_of(const std::string& name) {                    // "model.list.<block>. ..."
+    const size_t at = name.find("model.list.");
+    CC_CHECK(at == 0 && isdigit((unsigned char)name[11]), "conv parameter outside model.list.<block>: " + name);
+    return atoi(name.c_str() + 11);
+  }
   const PackedConv& pconv(const std::vector<std::string>& names, const std::vector<int>& groups, int cin_pad = 0) {
     std::string key;
     for (auto& n : names) key += n + "+";
@@ -339,7 +346,9 @@ struct Builder {
       CC_CHECK(b != Y->host.end(), "missing parameter " + n + ".bias");
       ws.push_back(&w->second); bs.push_back(&b->second);
     }
-    return Y->packed[key] = pack_convs(Y->dtype, ws, bs, groups, cin_pad, Y->wsplit);
+    bool split = Y->wsplit && block_of(names[0]) <= Y->split_last;
+    if (Y->wsplit && !split && Y->split_rest_k && ws[0]->shape.size() == 4 && ws[0]->shape[2] == Y->split_rest_k) split = true;
+    return Y->packed[key] = pack_convs(Y->dtype, ws, bs, groups, cin_pad, split);
   }
 
   Src src(const In& in) {
@@ -498,6 +507,7 @@ struct Builder {
   View elan4(const std::string& p, const std::vector<In>& ins, int hid, int cout) {   // RepNCSPELAN4 :107-125
     const int H = dimH(ins[0]), W = dimW(ins[0]);
     const int cat = new_buf(H, W, 8 * hid), o = new_buf(H, W, cout);
+    if (getenv("CLEARCAM_TAP_CSP")) P->taps["cat" + std::to_string(n_csp / 2)] = cat;     // tests: [y0 | y1 | y2 | y3] of the n-th RepNCSPELAN4
     conv(ins, pconv({p + ".cv1.conv"}, {1}), slice(whole(cat), 0, 4 * hid), 1, 1);
     csp_branch(p + ".cv2", slice(whole(cat), 2 * hid, 2 * hid), slice(whole(cat), 4 * hid, 2 * hid), hid);
     csp_branch(p + ".cv3", slice(whole(cat), 4 * hid, 2 * hid), slice(whole(cat), 6 * hid, 2 * hid), hid);
@@ -748,6 +758,14 @@ struct Builder {
     const View y21 = elan4(M + "21", {{y19, 0}, {y9, 0}}, a.e8_hidden, a.p5);
     head_level(M + "22.", 2, y21);
     P->taps["p3"] = y15.buf; P->taps["p4"] = y18.buf; P->taps["p5"] = y21.buf;
+    if (getenv("CLEARCAM_TAP_BLOCKS")) {                         // development: every block's output readable ("b<block>": the WHOLE buffer the
+      const std::pair<int, View> ys[] = {{2, y2}, {3, y3}, {4, y4}, {5, y5}, {6, y6}, {7, y7}, {8, y8}, {9, y9}, {12, y12}, {16, y16}, {19, y19}};   // view lives in)
+      for (auto& kv : ys) {
+        P->taps["b" + std::to_string(kv.first)] = kv.second.buf;
+        fprintf(stderr, "[clearcam] tap b%d: channels [%d, %d) of a %d-channel buffer\n", kv.first, kv.second.coff, kv.second.coff + kv.second.C, P->bufs[kv.second.buf].C);
+      }
+      P->taps["b1"] = b1;
+    }
     head_finish();
   }
 
@@ -1100,7 +1118,7 @@ int cc_device_count(int* n) { CC_API_BEGIN CC_HIP(hipGetDeviceCount(n)); CC_API_
 int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device) {
   CC_API_BEGIN
   CC_CHECK(h && size, "null argument");
-  CC_CHECK(dtype >= 0 && dtype <= 3, "dtype must be 0 (f32), 1 (f16), 2 (bf16) or 3 (f16 storage with split f16 weights)");
+  CC_CHECK(dtype >= 0 && dtype <= 4, "dtype must be 0 (f32), 1 (f16), 2 (bf16), 3 (f16 storage with split f16 weights) or 4 (... in the backbone only)");
   CC_CHECK(res > 0 && res % 32 == 0, "res must be a positive multiple of 32");
   const Arch* a = nullptr;
   for (const Arch& x : kArch) if (!strcmp(x.size, size)) a = &x;
@@ -1109,7 +1127,12 @@ int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device
   CC_CHECK(n > 0 && device >= 0 && device < n, "no such HIP device");
   CC_HIP(hipSetDevice(device));
   std::unique_ptr<cc_yolo> y(new cc_yolo());
-  y->arch = a; y->res = res; y->dtype = storage_dtype(dtype); y->wsplit = dtype == F16S; y->device = device;
+  y->arch = a; y->res = res; y->dtype = storage_dtype(dtype); y->wsplit = dtype == F16S || dtype == F16H; y->device = device;
+  if (dtype == F16H) {
+    const char* e = getenv("CLEARCAM_SPLIT_LAST");                   // development: the last block that carries the low plane
+    if (const char* k = getenv("CLEARCAM_SPLIT_REST_K")) y->split_rest_k = atoi(k);
+    y->split_last = e ? atoi(e) : !strcmp(size, "e") ? 29 : 9;       // the SPPELAN block closes the backbone (t/s/m/c: 9; e: 29)
+  }
   y->stream = pool_stream_get(device);
   CC_HIP(hipEventCreate(&y->ev0)); CC_HIP(hipEventCreate(&y->ev1));
   CC_HIP(hipHostMalloc((void**)&y->nonfinite_host, 64, hipHostMallocDefault)); *y->nonfinite_host = 0;
@@ -1370,7 +1393,7 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
   if (const char* path = getenv("CLEARCAM_PROFILE_CSV")) {   // per-launch table for tuning
     FILE* f = fopen(path, "w");
     if (f) {
-      fprintf(f, "op,kind,ms,M,Cout,Ktot,ks,stride,Cin,alg_gmac,tflops,gbytes_min,gbs\n");
+      fprintf(f, "op,kind,ms,M,Cout,Ktot,ks,stride,Cin,alg_gmac,tflops,gbytes_min,gbs,weight_planes\n");
       for (size_t i = 0; i < n; ++i) {
         const Op& op = P->ops[i];
         float t = 0; hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
@@ -1381,24 +1404,24 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
           const double in0 = avg ? (double)(c.Hin + 1) * (c.Win + 1) : (double)(c.Hin >> c.s0.shift) * (c.Win >> c.s0.shift);
           const double bytes = (double)c.B * in0 * c.s0.C * es + (double)c.B * (c.Hin >> c.s1.shift) * (c.Win >> c.s1.shift) * c.s1.C * es
                              + M * c.Cout * (c.out_f32 ? 4 : es) + (c.res ? M * c.Cout * es : 0) + (double)c.Cout * c.Ktot * es;
-          fprintf(f, "%zu,%s,%.4f,%.0f,%d,%d,%d,%d,%d,%.4f,%.1f,%.4f,%.0f\n", i, avg ? "conv_avg" : "conv", t, M, c.Cout, c.Ktot, c.ks, c.stride, c.Cin,
-                  op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9);
+          fprintf(f, "%zu,%s,%.4f,%.0f,%d,%d,%d,%d,%d,%.4f,%.1f,%.4f,%.0f,%d\n", i, avg ? "conv_avg" : "conv", t, M, c.Cout, c.Ktot, c.ks, c.stride, c.Cin,
+                  op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9, 1 + c.split);
         } else if (op.kind == 1) {
           const PoolP& q = op.pool; const double es = dtype_size(h->dtype);
           const double bytes = ((double)q.B * q.H * q.W + (double)q.B * q.Ho * q.Wo) * q.C * es;
-          fprintf(f, "%zu,pool%d_k%d_s%d,%.4f,%.0f,%d,0,%d,%d,%d,0,0,%.4f,%.0f\n", i, q.mode, q.k, q.stride, t, (double)q.B * q.Ho * q.Wo, q.C, q.k, q.stride, q.C,
+          fprintf(f, "%zu,pool%d_k%d_s%d,%.4f,%.0f,%d,0,%d,%d,%d,0,0,%.4f,%.0f,0\n", i, q.mode, q.k, q.stride, t, (double)q.B * q.Ho * q.Wo, q.C, q.k, q.stride, q.C,
                   bytes / 1e9, bytes / (t * 1e-3) / 1e9);
         } else if (op.kind == 5) {
           const StemP& q = op.stem; const double M = (double)q.pre.B * q.Ho * q.Wo, es = dtype_size(h->dtype);
           const double bytes = (double)q.pre.B * q.pre.H * q.pre.W * 3 * (q.pre.frame_f32 ? 4 : 1) + M * q.Cout * es;
-          fprintf(f, "%zu,stem_fused,%.4f,%.0f,%d,27,3,2,3,%.4f,%.1f,%.4f,%.0f\n", i, t, M, q.Cout, op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12,
-                  bytes / 1e9, bytes / (t * 1e-3) / 1e9);
+          fprintf(f, "%zu,stem_fused,%.4f,%.0f,%d,27,3,2,3,%.4f,%.1f,%.4f,%.0f,%d\n", i, t, M, q.Cout, op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12,
+                  bytes / 1e9, bytes / (t * 1e-3) / 1e9, q.w_lo ? 2 : 1);
         } else if (op.kind == 6) {
           const CspP& q = op.csp; const double M = (double)q.B * q.H * q.W, es = dtype_size(h->dtype);
           const double bytes = M * 4 * q.hid * es + (double)(8 + 18) * q.hid * q.hid * es;     // x in, out out, the four weight matrices
-          fprintf(f, "%zu,csp_fused,%.4f,%.0f,%d,%d,3,1,%d,%.4f,%.1f,%.4f,%.0f\n", i, t, M, 2 * q.hid, (8 + 18) * q.hid, 2 * q.hid, op.alg_macs / 1e9,
-                  2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9);
-        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : (op.kind == 7 ? "head_tail" : "topk_nms")), t);
+          fprintf(f, "%zu,csp_fused,%.4f,%.0f,%d,%d,3,1,%d,%.4f,%.1f,%.4f,%.0f,%d\n", i, t, M, 2 * q.hid, (8 + 18) * q.hid, 2 * q.hid, op.alg_macs / 1e9,
+                  2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9, 1 + q.split);
+        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : (op.kind == 7 ? "head_tail" : "topk_nms")), t);
       }
       fclose(f);
     }

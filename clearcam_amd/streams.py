@@ -297,7 +297,7 @@ def main() -> None:
     ap.add_argument("--res", type=int, default=640)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--dtype", default="f16s")
+    ap.add_argument("--dtype", default="f16h")
     ap.add_argument("--resident", action="store_true", help="frames stay in HBM (no PCIe upload)")
     ap.add_argument("--thresh", type=float, default=0.25, help="tracker score threshold (clearcam's detection threshold setting)")
     ap.add_argument("--cls-bias-shift", type=float, default=0.0, help="move the synthetic class-logit biases (sparser detections)")

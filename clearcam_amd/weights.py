@@ -271,14 +271,15 @@ def conditioned_yolov9_state_dict(size: str = "c", seed: int = 1234, table=None,
     the larger one by construction: its 3x3 filters are low-pass, which attenuates white activation-rounding noise at
     every layer but passes the smooth, signal-correlated error of a perturbed filter (per-block table in DESIGN.md section 5)."""
     if table is None:
-        if size not in _COND:
+        tag = size if seed == 1234 else f"{size}_s{seed}"          # the table is data-dependent: one per (size, seed) of base filters
+        if tag not in _COND:
             import os
-            path = os.path.join(os.path.dirname(__file__), "assets", f"synth_cond_{size}.npz")
+            path = os.path.join(os.path.dirname(__file__), "assets", f"synth_cond_{tag}.npz")
             if not os.path.exists(path):
-                raise FileNotFoundError(f"no conditioned checkpoint table for size '{size}' ({path}); run tools/calibrate_synth.py cond {size}")
+                raise FileNotFoundError(f"no conditioned checkpoint table for size '{size}' seed {seed} ({path}); run tools/calibrate_synth.py cond {size} --seed {seed}")
             with np.load(path) as z:
-                _COND[size] = unpack_cond_table(size, z["gain"], z["bias"], z["jitter"])
-        table = _COND[size]
+                _COND[tag] = unpack_cond_table(size, z["gain"], z["bias"], z["jitter"])
+        table = _COND[tag]
     sd = conditioned_base_weights(size, seed)
     for key in list(sd):
         if not key.endswith(".weight") or sd[key].ndim != 4 or ".dfl." in key:

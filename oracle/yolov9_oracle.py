@@ -438,6 +438,27 @@ def parity_summary(refs: np.ndarray, gots: np.ndarray, box_tol: float, dec_ref: 
         both = (dec_ref[..., 4] > 0) & (dec_got[..., 4] > 0)
         ae = np.abs(dec_ref[..., :4] - dec_got[..., :4]).max(-1)[both]
         out.update(anchors_both_over_thr=int(both.sum()), anchor_box_err_px_p50=float(np.quantile(ae, 0.5)) if len(ae) else 0.0,
-                   anchor_box_err_px_p99=float(np.quantile(ae, 0.99)) if len(ae) else 0.0, anchor_box_err_px_max=float(ae.max()) if len(ae) else 0.0,
+                   anchor_box_err_px_p99=float(np.quantile(ae, 0.99)) if len(ae) else 0.0, anchor_box_err_px_p999=float(np.quantile(ae, 0.999)) if len(ae) else 0.0,
+                   anchor_box_err_px_max=float(ae.max()) if len(ae) else 0.0, anchors_over_tol=int((ae > box_tol).sum()),
                    anchor_score_err_max=float(np.abs(dec_ref[..., 4] - dec_got[..., 4])[both].max()) if both.any() else 0.0)
     return out
+
+
+def tolerance_bars(s: dict) -> dict:
+    """The bars a 16-bit TOLERANCE mode (f16 activations, weights exact or nearly exact: dtypes "f16s" / "f16h") is held to against this
+    f32 oracle on a checkpoint whose float32 weights are not pre-rounded, from a ``parity_summary`` with the decoded rows given.  The
+    tolerance is the north star's 1e-3 x max(H, W) px (``box_tol``), applied at three levels:
+
+      detections   >= 98.5 % of the rows strictly matched (same class, IoU >= 0.9, all four coordinates within the tolerance), rows whose
+                   own score sits within 2e-3 of the 0.25 threshold left out (>= 97.5 % with every row counted); scores within 2e-3
+      anchors      99.9 % of the anchors both sides score over the threshold within the tolerance
+      tail         no anchor beyond 1.5 x the tolerance.  f16 ACTIVATION rounding has a tail: rounding flips cascade (one flipped element
+                   flips ~50 downstream), so two correct implementations are independent noise realisations within three layers, and an
+                   ill-conditioned P5 region of one frame can read 0.6 px where the typical worst anchor of a frame set reads 0.2-0.35
+                   ("The tail"); the modes with rounded weights (plain f16 / bf16) reach 0.8-1.2 / 8 px.
+    """
+    tol = s["box_tol_px"]
+    bars = {"detections": s["match_frac_clear_of_threshold"] >= 0.985 and s["match_frac"] >= 0.975 and s["anchor_score_err_max"] <= 2e-3,
+            "anchors": s["anchor_box_err_px_p999"] <= tol, "tail": s["anchor_box_err_px_max"] <= 1.5 * tol}
+    bars["all"] = all(bars.values())
+    return bars

@@ -49,8 +49,11 @@ def test_weights_are_exact_in_both_16bit_storage_types(sd):
             assert torch.equal(t.to(torch.float16).float(), t), k           # 8 significant bits, exponents far inside f16's range
 
 
-def test_committed_conditioning_report():
-    rep = json.load(open(os.path.join(os.path.dirname(W.__file__), "assets", "synth_cond_report.json")))["c"]
+@pytest.mark.parametrize("tag", ["c", "c_s7", "c_s99"])
+def test_committed_conditioning_report(tag):
+    """One calibration table per checkpoint (the gains and bias shifts are data-dependent): seed 1234 and the two further checkpoints the
+    GPU parity tests of the tolerance modes run on (tools/calibrate_synth.py cond c --seed N)."""
+    rep = json.load(open(os.path.join(os.path.dirname(W.__file__), "assets", "synth_cond_report.json")))[tag]
     for where, g in rep["f32_perturbation_gain_at_p3_p4_p5"].items():
         assert max(g) <= 2.0, (where, g)                                     # white noise injected anywhere does not grow
     assert rep["bf16_storage_emulation"]["match_frac"] >= 0.95 and rep["f16_storage_emulation"]["match_frac"] >= 0.95

@@ -60,3 +60,30 @@ def test_per_anchor_statistics_use_only_anchors_both_sides_score():
     s = parity_summary(np.zeros((2, 300, 6), np.float32), np.zeros((2, 300, 6), np.float32), 0.64, dec_a, dec_b)
     assert s["anchors_both_over_thr"] == 40 and abs(s["anchor_box_err_px_p50"] - 0.25) < 1e-3
     assert abs(s["anchor_box_err_px_max"] - 3.25) < 1e-3 and abs(s["anchor_score_err_max"] - 1e-4) < 1e-6
+
+
+def test_tolerance_bars_levels():
+    """tolerance_bars: detections (strict matches, scores), 99.9 % of the anchors within the tolerance, no anchor beyond 1.5x."""
+    from oracle.yolov9_oracle import tolerance_bars
+    rng = np.random.default_rng(4)
+    a = np.stack([_dets(60, s) for s in range(4)])
+    dec_a = np.zeros((4, 3000, 6), np.float32)
+    dec_a[..., :4] = rng.uniform(0, 600, (4, 3000, 4)); dec_a[..., 4] = 0.5
+
+    def bars(shift, outliers=(), n_big=0, score=0.0):
+        b = a.copy(); b[..., :4] += np.float32(shift); b[:, :60, 4] += np.float32(score)
+        dec_b = dec_a.copy(); dec_b[..., :4] += np.float32(shift); dec_b[..., 4] += np.float32(score)
+        for i, e in enumerate(outliers):
+            dec_b[0, i, 0] += np.float32(e)
+        dec_b[1, :n_big, 1] += np.float32(0.7)
+        return tolerance_bars(parity_summary(a, b, 0.64, dec_a, dec_b))
+
+    assert bars(0.2)["all"]
+    assert bars(0.2, outliers=(0.5, 0.6))["all"]                          # two anchors of 12000 at 0.7-0.8 px: inside the tail bound
+    t = bars(0.2, outliers=(0.9,))
+    assert not t["tail"] and t["anchors"] and t["detections"] and not t["all"]      # one anchor at 1.1 px
+    t = bars(0.2, n_big=30)
+    assert not t["anchors"] and t["tail"] and not t["all"]                # 0.25 % of the anchors at 0.9 px
+    t = bars(0.7)
+    assert not t["detections"] and not t["all"]                           # every row off by more than the tolerance
+    assert not bars(0.2, score=3e-3)["detections"]                        # scores off by 3e-3

@@ -2,6 +2,7 @@
 
     python tools/calibrate_synth.py                 # the chaotic checkpoint's LSUV scales -> assets/synth_scales.json
     python tools/calibrate_synth.py cond c          # the well-conditioned checkpoint      -> assets/synth_cond_<size>.npz
+    python tools/calibrate_synth.py cond c --seed 7 # ... from another seed's base filters -> assets/synth_cond_<size>_s<seed>.npz
                                                     #   + measured conditioning            -> assets/synth_cond_report.json
 
 A 144-conv SiLU stack without normalisation either explodes or dies under any fixed init gain, so
@@ -162,16 +163,21 @@ def conditioning_report(size: str, sd, res: int = 640, n_frames: int = 12):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cond":
-        sizes = sys.argv[2:] or ["c"]
+        argv = sys.argv[2:]
+        seed = 1234
+        if "--seed" in argv:                                        # further checkpoints: assets/synth_cond_<size>_s<seed>.npz
+            seed = int(argv[argv.index("--seed") + 1]); del argv[argv.index("--seed"):argv.index("--seed") + 2]
+        sizes = argv or ["c"]
         rpath = os.path.join(ASSETS, "synth_cond_report.json")
         report = json.load(open(rpath)) if os.path.exists(rpath) else {}
-        for s in sizes:
-            table = calibrate_conditioned(s)
-            np.savez_compressed(os.path.join(ASSETS, f"synth_cond_{s}.npz"), **W.pack_cond_table(s, table))
-            W._COND.pop(s, None)
-            report[s] = conditioning_report(s, W.conditioned_yolov9_state_dict(s))
-            report[s]["design"] = {"eps": W.COND_EPS, "preact_std": W.COND_STD, "dfl_std": W.COND_DFL_STD, "dfl_ramp": W.COND_DFL_RAMP, "cls_bias": W.COND_CLS_BIAS, "quantile": W.COND_Q, "active_classes": W.COND_ACTIVE_CLASSES}
-            print(s, json.dumps(report[s], indent=1), flush=True)
+        for size in sizes:
+            tag = size if seed == 1234 else f"{size}_s{seed}"
+            table = calibrate_conditioned(size, seed)
+            np.savez_compressed(os.path.join(ASSETS, f"synth_cond_{tag}.npz"), **W.pack_cond_table(size, table))
+            W._COND.pop(tag, None)
+            report[tag] = conditioning_report(size, W.conditioned_yolov9_state_dict(size, seed))
+            report[tag]["design"] = {"eps": W.COND_EPS, "preact_std": W.COND_STD, "dfl_std": W.COND_DFL_STD, "dfl_ramp": W.COND_DFL_RAMP, "cls_bias": W.COND_CLS_BIAS, "quantile": W.COND_Q, "active_classes": W.COND_ACTIVE_CLASSES}
+            print(tag, json.dumps(report[tag], indent=1), flush=True)
         json.dump(report, open(rpath, "w"), indent=1, sort_keys=True)
         print("wrote", rpath)
     elif len(sys.argv) > 1 and sys.argv[1] == "report-chaotic":

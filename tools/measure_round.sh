@@ -8,7 +8,7 @@
 # and run the bench LAST (step 1 is executed after step 4 for that reason).
 set -u
 tag=${1:-r02d}
-export CLEARCAM_BENCH_DTYPE=${CLEARCAM_BENCH_DTYPE:-f16s}      # the storage mode every record below is taken in (bench.py's default)
+export CLEARCAM_BENCH_DTYPE=${CLEARCAM_BENCH_DTYPE:-f16h}      # the storage mode every record below is taken in (bench.py's default)
 dt=$CLEARCAM_BENCH_DTYPE
 export TMPDIR=/tmp PYTHONPATH=$PWD
 root=$PWD
@@ -29,7 +29,7 @@ tot = {}
 for r in rows:
     tot[fam(r["Name"])] = tot.get(fam(r["Name"]), 0.0) + float(r["TotalDurationNs"]) / 1e6
 import torch
-dt = os.environ.get("CLEARCAM_BENCH_DTYPE", "f16s")
+dt = os.environ.get("CLEARCAM_BENCH_DTYPE", "f16h")
 rec = {"kernel_source_digest": kernel_source_digest(), "tag": tag, "replays": 10, "dtype": dt,
        "device_name": torch.cuda.get_device_name(0) if torch.cuda.is_available() else None,
        "command": f"rocprofv3 --kernel-trace --stats -- python tools/dev/plan_passes.py 9   (10 replays of the bench plan, YOLOv9-C {dt} B=64 640x640)",

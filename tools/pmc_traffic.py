@@ -3,7 +3,7 @@
     cd /tmp && export TMPDIR=/tmp && python $GRAFT_REPO_ROOT/tools/pmc_traffic.py [tag]
 
 Two separate counter passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains besides the kernel trace, as
-the GPU pool requires), each over `tools/dev/plan_passes.py N` = N replays of the bench plan (YOLOv9-C, B=64, 640x640, storage mode $CLEARCAM_BENCH_DTYPE, default f16s).
+the GPU pool requires), each over `tools/dev/plan_passes.py N` = N replays of the bench plan (YOLOv9-C, B=64, 640x640, storage mode $CLEARCAM_BENCH_DTYPE, default f16h).
 Per MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE count L2 memory-side requests (Infinity-Cache hits included),
 rocprofv3 reports them in KiB, and on gfx950 FETCH_SIZE reports HALF the bytes of wide coalesced (16 B per lane) reads —
 every conv / pool kernel here loads that way (global_load_lds_dwordx4 / dwordx4), so their read bytes are 2 x FETCH_SIZE;
@@ -60,7 +60,7 @@ def main():
             conv_r += r_b; conv_w += w_b
         elif "pool" in k:
             pool_r += r_b; pool_w += w_b
-    dtype = os.environ.get("CLEARCAM_BENCH_DTYPE", "f16s")
+    dtype = os.environ.get("CLEARCAM_BENCH_DTYPE", "f16h")
     rec = {"kernel_source_digest": kernel_source_digest(), "tag": tag, "dtype": dtype, "config": f"YOLOv9-C {dtype} B=64 640x640", "plan_replays_per_pass": replays,
            "conv_read_bytes_per_step": conv_r, "conv_write_bytes_per_step": conv_w, "conv_bytes_per_step": conv_r + conv_w,
            "pool_bytes_per_step": pool_r + pool_w,
