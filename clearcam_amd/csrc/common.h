@@ -14,8 +14,9 @@ namespace cc {
 enum DType : int { F32 = 0, F16 = 1, BF16 = 2 };
 // C-ABI dtype 3 ("f16s"): f16 activations, every conv weight carried as TWO f16 planes W = W_hi + W_lo (ConvP::split). Storage type F16.
 constexpr int F16S = 3;
-// C-ABI dtype 4 ("f16h"): as F16S for the detector's backbone (blocks 0-9), plain f16 weights with controlled rounding from block 10 on
-// (the neck and the head): weight rounding only moves boxes when many layers follow it ("Which layers need the low plane").
+// C-ABI dtype 4 ("f16h"): the low plane only where it is needed - the 1x1 convs of the detector's backbone (blocks 0-9) and the stem conv;
+// every other conv carries one f16 plane with controlled rounding, which balances a 3x3 filter's nine taps against each other and has
+// nothing to balance in a 1x1 ("Which layers need the low plane").
 constexpr int F16H = 4;
 inline int storage_dtype(int dt) { return dt == F16S || dt == F16H ? (int)F16 : dt; }
 

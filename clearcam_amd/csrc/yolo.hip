@@ -91,8 +91,9 @@ struct cc_yolo {
   const Arch* arch = nullptr;
   int res = 640, dtype = BF16, device = 0;              // dtype: STORAGE type of activations and weights
   int wsplit = 0;                                      // C-ABI dtype 3 ("f16s"): f16 storage, every conv weight as two f16 planes (ConvP::split)
-  int split_rest_k = 0;                                // development: past split_last, convs of this filter size keep the low plane too
-  int split_last = 1 << 30;                            // ... up to this block of the graph (dtype 4, "f16h": 9 - the backbone; later blocks carry one plane)
+  // ... dtype 3 ("f16s"): everywhere.  dtype 4 ("f16h"): every conv up to block split_all_last (the stem conv), the 1x1 convs up to block
+  // split_1x1_last (the backbone); everything else carries one plane with controlled rounding
+  int split_all_last = 1 << 30, split_1x1_last = 1 << 30;
   hipStream_t stream = nullptr;
   std::vector<hipStream_t> side;                       // streams of lanes 1.. while a plan is captured (run_ops_lanes)
   // Batches in flight (cc_yolo_submit / cc_yolo_wait): slot i > 0 has its own stream and its own plans (arena, graph), so the tail of
@@ -346,8 +347,9 @@ struct Builder {
       CC_CHECK(b != Y->host.end(), "missing parameter " + n + ".bias");
       ws.push_back(&w->second); bs.push_back(&b->second);
     }
-    bool split = Y->wsplit && block_of(names[0]) <= Y->split_last;
-    if (Y->wsplit && !split && Y->split_rest_k && ws[0]->shape.size() == 4 && ws[0]->shape[2] == Y->split_rest_k) split = true;
+    const int blk = block_of(names[0]);
+    const bool k1 = ws[0]->shape.size() == 4 && ws[0]->shape[2] == 1;
+    const bool split = Y->wsplit && (blk <= Y->split_all_last || (k1 && blk <= Y->split_1x1_last));
     return Y->packed[key] = pack_convs(Y->dtype, ws, bs, groups, cin_pad, split);
   }
 
@@ -448,13 +450,17 @@ struct Builder {
     static const bool dev = [] { const char* e = getenv("CLEARCAM_DEV"); return e && atoi(e) != 0; }();
     return dev ? getenv(name) : nullptr;
   }
-  bool fuse_csp(View in, int hid, int index) const {
+  bool fuse_csp(View in, int hid, int index, const std::string& r) {
     const char* e = getenv("CLEARCAM_FUSE_CSP");
     const int level = e ? atoi(e) : 2;
     if (level == 0 || (level == 1 && hid != 32)) return false;
     const char* only = dev_env("CLEARCAM_CSP_ONLY");                // development: fuse just this block (csp_debug.py)
     if (only && atoi(only) != index) return false;
-    return a.rep_n == 1 && csp_fused_supported(Y->dtype, hid, Y->wsplit) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0;
+    if (!(a.rep_n == 1 && csp_fused_supported(Y->dtype, hid, Y->wsplit) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0)) return false;
+    // the fused kernel takes ONE split flag for its four convs; in "f16h" the 1x1 convs of a backbone RepNCSP carry two planes and its
+    // 3x3 convs one: those blocks run as four launches
+    const int s0 = pconv({r + ".cv1.conv", r + ".cv2.conv"}, {1, 1}).split;
+    return pconv({r + ".m.list.0.cv1.conv"}, {1}).split == s0 && pconv({r + ".m.list.0.cv2.conv"}, {1}).split == s0 && pconv({r + ".cv3.conv"}, {1}).split == s0;
   }
   void csp_fused(const std::string& r, View in, View out, int hid) {
     Op op{}; op.kind = 6; CspP& q = op.csp;
@@ -484,7 +490,7 @@ struct Builder {
     const std::string r = p + ".list.0";
     const bool tap = getenv("CLEARCAM_TAP_CSP") != nullptr;          // tests: keep the block's tensors readable (costs arena)
     const std::string tn = "csp" + std::to_string(n_csp);
-    if (fuse_csp(in, hid, n_csp++)) {
+    if (fuse_csp(in, hid, n_csp++, r)) {
       const int u = new_buf(H, W, 2 * hid);
       if (tap) P->taps[tn + "_u"] = u;
       csp_fused(r, in, whole(u), hid);
@@ -1129,9 +1135,11 @@ int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device
   std::unique_ptr<cc_yolo> y(new cc_yolo());
   y->arch = a; y->res = res; y->dtype = storage_dtype(dtype); y->wsplit = dtype == F16S || dtype == F16H; y->device = device;
   if (dtype == F16H) {
-    const char* e = getenv("CLEARCAM_SPLIT_LAST");                   // development: the last block that carries the low plane
-    if (const char* k = getenv("CLEARCAM_SPLIT_REST_K")) y->split_rest_k = atoi(k);
-    y->split_last = e ? atoi(e) : !strcmp(size, "e") ? 29 : 9;       // the SPPELAN block closes the backbone (t/s/m/c: 9; e: 29)
+    // development switches (tools/dev/hybrid_eval.py, test_split_boundaries): the last block whose every conv / whose 1x1 convs carry the low plane
+    const char *ea = getenv("CLEARCAM_SPLIT_ALL_LAST"), *e1 = getenv("CLEARCAM_SPLIT_1X1_LAST");
+    const bool e = !strcmp(size, "e");                               // "e": block 1 is the first conv, block 29 the SPPELAN
+    y->split_all_last = ea ? atoi(ea) : (e ? 1 : 0);
+    y->split_1x1_last = e1 ? atoi(e1) : (e ? 29 : 9);
   }
   y->stream = pool_stream_get(device);
   CC_HIP(hipEventCreate(&y->ev0)); CC_HIP(hipEventCreate(&y->ev1));

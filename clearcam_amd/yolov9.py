@@ -20,9 +20,10 @@ from .helpers import Tensor, as_numpy
 from .weights import load_safetensors
 
 # "f16s": f16 activations with every conv weight carried as two f16 planes (W = W_hi + W_lo, ~22 significant bits, f32 accumulation):
-# the 16-bit mode whose WEIGHTS are exact to f32 for any checkpoint.  "f16h" keeps the second plane only where it is needed - the
-# backbone (blocks 0-9); the neck and head carry one f16 plane with controlled rounding - and stays as close to the f32 oracle on three
-# independently calibrated un-rounded checkpoints at 1.27x the frame rate.  Plain f16 / bf16 round every weight
+# the 16-bit mode whose WEIGHTS are exact to f32 for any checkpoint.  "f16h" keeps the second plane only where it is needed - the 1x1
+# convs of the backbone (blocks 0-9) and the stem conv; every other conv carries one f16 plane with controlled rounding (which balances a
+# 3x3 filter's taps and has nothing to balance in a 1x1) - and stays as close to the f32 oracle on three independently calibrated
+# un-rounded checkpoints at 1.4x the frame rate.  Plain f16 / bf16 round every weight
 # to 11 / 8 bits: speed modes.  "f32" is the exact-arithmetic parity mode.
 DTYPES = {"f32": 0, "float32": 0, "f16": 1, "float16": 1, "half": 1, "bf16": 2, "bfloat16": 2, "f16s": 3, "f16_split": 3, "f16h": 4}
 MAX_DET = 300
@@ -31,9 +32,9 @@ MAX_DET = 300
 class YOLOv9:
     def __init__(self, size: str = "t", res: int = 1280, state_dict: Optional[Dict[str, np.ndarray]] = None,
                  weights: Optional[str] = None, dtype: str = "f16h", device: int = 0):
-        """dtype: "f16h" (default) - f16 activations, split f16 weights in the backbone, one controlled-rounded f16 plane after it:
-        detections within the reference tolerance on un-rounded float32 checkpoints; "f16s" - split weights in every conv (weights exact
-        to f32 whatever the checkpoint; 0.79x the rate); "f32" - the exact-arithmetic parity mode (5x slower); "f16" / "bf16" - speed modes whose 11 / 8-bit weight
+        """dtype: "f16h" (default) - f16 activations, split f16 weights in the backbone's 1x1 convs and the stem, one controlled-rounded
+        f16 plane elsewhere: detections within the reference tolerance on un-rounded float32 checkpoints; "f16s" - split weights in every
+        conv (weights exact to f32 whatever the checkpoint; 0.7x the rate); "f32" - the exact-arithmetic parity mode (5x slower); "f16" / "bf16" - speed modes whose 11 / 8-bit weight
         rounding (controlled rounding: filter sums preserved) moves boxes by up to a pixel / several pixels on the conditioned synthetic checkpoint.  f16
         storage saturates at 65504: a checkpoint whose activations exceed that needs "bf16" or "f32"."""
         if size not in YOLO_ARCH and size != "e":

@@ -21,12 +21,13 @@ extern "C" {
 #define CC_DTYPE_F32 0   /* parity mode: f32 storage, exact-f32 MFMA (157 TFLOP/s class)                                             */
 #define CC_DTYPE_F16 1   /* speed mode:  f16 storage (activations AND weights rounded to 11 bits), f32 accumulate                    */
 #define CC_DTYPE_BF16 2  /* speed mode:  bf16 storage (8 bits), f32 accumulate                                                       */
-#define CC_DTYPE_F16S 3  /* tolerance mode at MFMA rate (bench default; detector only): f16 activations, every conv weight carried as */
+#define CC_DTYPE_F16S 3  /* tolerance mode at MFMA rate (detector only): f16 activations, every conv weight carried as */
                          /* TWO f16 planes W = W_hi + W_lo (~22 bits) multiplied into the same f32 accumulator - detections stay      */
                          /* within the reference tolerance for any float32 checkpoint at twice the MFMA issue of CC_DTYPE_F16        */
-#define CC_DTYPE_F16H 4  /* CC_DTYPE_F16S in the detector's backbone (blocks up to the SPPELAN), CC_DTYPE_F16 weights (controlled     */
-                         /* rounding) in the neck and the head: measured as close to f32 as CC_DTYPE_F16S on un-rounded checkpoints   */
-                         /* (weight rounding moves boxes only when many layers follow it) at 1.4x instead of 2x the MFMA issue       */
+#define CC_DTYPE_F16H 4  /* CC_DTYPE_F16S where it is needed: two planes for the 1x1 convs of the detector's backbone (blocks up to the     */
+                         /* SPPELAN) and the stem conv, one controlled-rounded f16 plane for every other conv (controlled rounding balances  */
+                         /* a 3x3 filter's taps; a 1x1 has nothing to balance).  Measured as close to f32 as CC_DTYPE_F16S on un-rounded      */
+                         /* checkpoints at 1.17x instead of 2x the MFMA issue of CC_DTYPE_F16 (bench default)                              */
 
 #define CC_MAX_DET 300   /* rows per frame of the detector output (detection/yolov9.py:439) */
 

@@ -427,8 +427,8 @@ def test_detect_16bit_modes_with_unrounded_weights(dtype):
 
 @pytest.mark.parametrize("dtype", ["f16h", "f16s"])
 def test_detect_split_weight_mode_with_unrounded_weights(dtype):
-    """dtype "f16s" (f16 activations, every conv's weights as two f16 planes) and "f16h" (two planes in the backbone, one controlled-rounded
-    plane in the neck and head: bench.py's default) on the float32 checkpoint AS IT IS - weights not pre-rounded to 16-bit-exact values,
+    """dtype "f16s" (f16 activations, every conv's weights as two f16 planes) and "f16h" (two planes in the backbone's 1x1 convs and the stem, one controlled-rounded
+    plane elsewhere - see clearcam_amd/yolov9.py: bench.py's default) on the float32 checkpoint AS IT IS - weights not pre-rounded to 16-bit-exact values,
     which is what a trained checkpoint looks like (detection/yolov9.py:372-373 loads f32 safetensors) - against the F32 ORACLE at the bench
     configuration (64 frames): >= 98.5 % strict matches clear of the threshold, scores within 2e-3, P3..P5 within 4e-3, 99.9 % of the anchors
     within 1e-3 * max(H, W) = 0.64 px and none beyond 1.5x that (oracle.yolov9_oracle.tolerance_bars).  Measured on this frame set: the worst
@@ -460,16 +460,17 @@ def test_tolerance_modes_on_other_checkpoints(seed):
 
 
 def test_backbone_split_boundary(monkeypatch, sd_t):
-    """dtype "f16h" is "f16s" up to a block and "f16" after it, nothing else: with the boundary past the last block its rows are f16s's
-    bit for bit, with it before the first block plain f16's (development switch CLEARCAM_SPLIT_LAST, read when the handle is created);
-    the default boundary (block 9, the SPPELAN) gives rows of its own."""
+    """dtype "f16h" is "f16s" in some convs and "f16" in the others, nothing else: with every conv up to the last block carrying the low plane
+    its rows are f16s's bit for bit, with none plain f16's (development switches CLEARCAM_SPLIT_ALL_LAST / CLEARCAM_SPLIT_1X1_LAST, read when
+    the handle is created); the default (the stem conv and the backbone's 1x1 convs) gives rows of its own."""
     frames = noise_frames(5, 2, 320, 320)
     rows = {}
-    for name, dt, last in (("f16s", "f16s", None), ("f16", "f16", None), ("all", "f16h", "99"), ("none", "f16h", "-1"), ("default", "f16h", None)):
-        if last is None:
-            monkeypatch.delenv("CLEARCAM_SPLIT_LAST", raising=False)
-        else:
-            monkeypatch.setenv("CLEARCAM_SPLIT_LAST", last)
+    for name, dt, last in (("f16s", "f16s", None), ("f16", "f16", None), ("all", "f16h", ("99", "99")), ("none", "f16h", ("-1", "-1")), ("default", "f16h", None)):
+        for k, env in enumerate(("CLEARCAM_SPLIT_ALL_LAST", "CLEARCAM_SPLIT_1X1_LAST")):
+            if last is None:
+                monkeypatch.delenv(env, raising=False)
+            else:
+                monkeypatch.setenv(env, last[k])
         m = _yolo("t", 320, sd_t, dt)
         m.detect_batch(frames)
         rows[name] = np.concatenate([m.get_tensor("decoded")[..., :4].ravel(), m.get_tensor("p5").ravel()])    # every anchor's box + the P5 map
