@@ -5,9 +5,9 @@
 
 One "step" = one pass of the detect hot path (letterbox -> 144 convs -> decode -> top-300 + mask NMS)
 over one batch of 64 synthetic 640x640 BGR uint8 frames that are already resident in HBM.  The headline storage mode is
-"f16h": f16 activations; the backbone's conv weights (blocks 0-9, where weight rounding is amplified by everything downstream) carried
-as two f16 planes (W_hi + W_lo, f32 accumulation), the neck's and head's as one f16 plane with controlled rounding - detections
-stay inside the reference tolerance with UN-ROUNDED float32 weights on three independently calibrated checkpoints (measured in
+"f16h": f16 activations; the stem conv's and the backbone's 1x1 convs' weights (blocks 0-9: where weight rounding is amplified by everything
+downstream, and the filters controlled rounding cannot balance) carried as two f16 planes (W_hi + W_lo, f32 accumulation), every other
+conv's as one f16 plane with controlled rounding - detections stay inside the reference tolerance with UN-ROUNDED float32 weights on three independently calibrated checkpoints (measured in
 this run: `parity`).  "f16s" (two planes everywhere: weights exact to f32 for any checkpoint), plain f16 / bf16 (weights rounded to
 11 / 8 bits, speed modes) and f32 (exact arithmetic) are reported beside it.  The K timed steps are
 submitted round robin to `--in-flight` (default 3) slots of one handle (cc_yolo_submit: own stream, arena and graph
@@ -43,7 +43,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16s": 2500.0, "f16h": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 MFMA_PER_MAC = {"f16s": 2.0}                                    # split weights: two matrix instructions per algorithmic multiply-add
-                                                                # ("f16h": only the backbone's convs - read off the per-launch table's weight_planes)
+                                                                # ("f16h": only the stem and the backbone's 1x1 convs - read off the per-launch table's weight_planes)
 HBM_PEAK = 8.0e12
 FLOP_PER_FRAME_C640 = 2 * 51.068e9
 
@@ -190,8 +190,8 @@ def measured_parity(device_index: int, n_cond: int = 16, n_chaotic: int = 4) -> 
     out["worst_anchor_box_err_px_with_unrounded_weights"] = {dt: max(out[label][dt]["anchor_box_err_px_max"] for label in unrounded) for dt in modes}
     out["holds_tolerance_note"] = ("99.9 % of the anchors within 0.64 px and none beyond 0.96 px, scores within 2e-3, >= 98.5 % strict matches clear of the threshold, against the "
                                    "f32 oracle on the conditioned checkpoint with its float32 weights NOT pre-rounded; f16 / bf16 round their weights with controlled rounding "
-                                   "(yolo.hip round_controlled: filter sums preserved), f16s carries them as two f16 planes, f16h as two planes in the backbone "
-                                   "(blocks 0-9) and one controlled-rounded plane after it; three independently calibrated checkpoints, all must hold")
+                                   "(yolo.hip round_controlled: filter sums preserved), f16s carries them as two f16 planes, f16h as two planes in the stem conv and the backbone's "
+                                   "1x1 convs (blocks 0-9) and one controlled-rounded plane elsewhere; three independently calibrated checkpoints, all must hold")
     return out
 
 
@@ -448,7 +448,7 @@ def main() -> None:
     ap.add_argument("--height", type=int, default=0, help="source frame height (default: res)")
     ap.add_argument("--width", type=int, default=0, help="source frame width (default: res)")
     ap.add_argument("--dtype", default="f16h", choices=["f16h", "f16s", "bf16", "f16", "f32"],
-                    help="storage mode.  f16h (default): f16 activations, the backbone's conv weights as two f16 planes, one controlled-rounded plane after it - "
+                    help="storage mode.  f16h (default): f16 activations, the stem's and the backbone's 1x1 convs' weights as two f16 planes, one controlled-rounded plane elsewhere - "
                          "holds the parity yardstick with un-rounded float32 weights (DESIGN.md section 5); f16s: two planes in every conv.  f16 / bf16: speed modes (weights rounded to 11 / 8 bits); f32: exact")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight (cc_yolo_submit on that many slots of one handle: the last layers of one batch overlap the first "

@@ -29,16 +29,37 @@ def test_same_keys_and_shapes_as_the_reference_checkpoint(sd, sd_c):
     assert all(sd[k].shape == sd_c[k].shape and sd[k].dtype == np.float32 for k in sd)
 
 
+def _digest(d):
+    h = hashlib.sha256()
+    for k in sorted(d):
+        h.update(np.ascontiguousarray(d[k]).tobytes())
+    return h.hexdigest()[:16]
+
+
 def test_deterministic(sd):
     again = W.conditioned_yolov9_state_dict("c", 1234)
     assert all(np.array_equal(sd[k], again[k]) for k in sd)
     other = W.conditioned_yolov9_state_dict("c", 99)
     assert not np.array_equal(sd["model.list.4.cv1.conv.weight"], other["model.list.4.cv1.conv.weight"])
-    h = hashlib.sha256()
-    for k in sorted(sd):
-        h.update(np.ascontiguousarray(sd[k]).tobytes())
     # the seeded draws are PCG64 (platform independent); the digest pins generator + committed table together
-    assert h.hexdigest()[:16] == open(os.path.join(os.path.dirname(__file__), "golden", "synth_cond_c.sha256")).read().strip()
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    assert _digest(sd) == open(os.path.join(golden, "synth_cond_c.sha256")).read().strip()
+
+
+@pytest.mark.parametrize("seed", [7, 99])
+def test_further_checkpoints_are_pinned_and_16bit_exact(seed):
+    """The two further conditioned checkpoints (own calibration tables: assets/synth_cond_c_s<seed>.npz): pinned by digest, weights exact in
+    both 16-bit storage types in the exact=True form, un-rounded (and different) in the exact=False form the tolerance-mode tests use."""
+    d = W.conditioned_yolov9_state_dict("c", seed)
+    assert _digest(d) == open(os.path.join(os.path.dirname(__file__), "golden", f"synth_cond_c_s{seed}.sha256")).read().strip()
+    raw = W.conditioned_yolov9_state_dict("c", seed, exact=False)
+    k = "model.list.4.cv1.conv.weight"
+    t = torch.from_numpy(d[k])
+    assert torch.equal(t.to(torch.float16).float(), t) and torch.equal(t.to(torch.bfloat16).float(), t)
+    r = torch.from_numpy(raw[k])
+    assert not torch.equal(r.to(torch.float16).float(), r) and float((r - t).abs().max()) <= float(t.abs().max()) * 2.0 ** -8
+    with pytest.raises(FileNotFoundError):
+        W.conditioned_yolov9_state_dict("c", 5)                              # no table for this seed: calibrate first
 
 
 def test_weights_are_exact_in_both_16bit_storage_types(sd):

@@ -432,9 +432,9 @@ def test_detect_split_weight_mode_with_unrounded_weights(dtype):
     which is what a trained checkpoint looks like (detection/yolov9.py:372-373 loads f32 safetensors) - against the F32 ORACLE at the bench
     configuration (64 frames): >= 98.5 % strict matches clear of the threshold, scores within 2e-3, P3..P5 within 4e-3, 99.9 % of the anchors
     within 1e-3 * max(H, W) = 0.64 px and none beyond 1.5x that (oracle.yolov9_oracle.tolerance_bars).  Measured on this frame set: the worst
-    anchor reads 0.629 px (f16s) / 0.648 px (f16h) - the SAME anchor of frame 20, an ill-conditioned P5 region where f16 activation rounding
-    (identical in both modes: the backbone's bits are shared) is amplified 3x over the typical worst case; every other frame set measured
-    (tools/dev/hybrid_eval.py, three checkpoints) stays below 0.47 px in both modes."""
+    anchor reads 0.629 px in f16s (and 0.648 px in f16h's first form, which split every backbone conv and so shared f16s's backbone bits) - one
+    anchor of frame 20, an ill-conditioned P5 region where this realisation of the f16 ACTIVATION rounding is amplified 3x over the typical worst
+    case; every other frame set measured (tools/dev/hybrid_eval.py, three checkpoints) stays below 0.47 px in both modes."""
     frames = noise_frames(1, 64, 640, 640)
     sd, ref, feats, dec_ref = conditioned_case(frames, exact=False)
     m = _yolo("c", 640, sd, dtype)
