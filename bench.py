@@ -188,6 +188,9 @@ def measured_parity(device_index: int, n_cond: int = 16, n_chaotic: int = 4) -> 
     unrounded = ("weights_unrounded", "weights_unrounded_checkpoint_b", "weights_unrounded_checkpoint_c")
     out["holds_tolerance_with_unrounded_weights"] = {dt: all(holds(out[label][dt]) for label in unrounded) for dt in modes}
     out["worst_anchor_box_err_px_with_unrounded_weights"] = {dt: max(out[label][dt]["anchor_box_err_px_max"] for label in unrounded) for dt in modes}
+    # the stricter form the bars had until round 4 - EVERY anchor within the tolerance - reported, not part of `holds`: the worst anchor of a
+    # frame set is a heavy-tailed draw of the f16 activation rounding ("The tail")
+    out["every_anchor_within_tolerance_with_unrounded_weights"] = {dt: all(out[label][dt]["anchors_over_tol"] == 0 for label in unrounded) for dt in modes}
     out["holds_tolerance_note"] = ("99.9 % of the anchors within 0.64 px and none beyond 0.96 px, scores within 2e-3, >= 98.5 % strict matches clear of the threshold, against the "
                                    "f32 oracle on the conditioned checkpoint with its float32 weights NOT pre-rounded; f16 / bf16 round their weights with controlled rounding "
                                    "(yolo.hip round_controlled: filter sums preserved), f16s carries them as two f16 planes, f16h as two planes in the stem conv and the backbone's "
