@@ -27,7 +27,7 @@ extern "C" {
 #define CC_DTYPE_F16H 4  /* CC_DTYPE_F16S where it is needed: two planes for the 1x1 convs of the detector's backbone (blocks up to the     */
                          /* SPPELAN) and the stem conv, one controlled-rounded f16 plane for every other conv (controlled rounding balances  */
                          /* a 3x3 filter's taps; a 1x1 has nothing to balance).  Measured as close to f32 as CC_DTYPE_F16S on un-rounded      */
-                         /* checkpoints at 1.17x instead of 2x the MFMA issue of CC_DTYPE_F16 (bench default)                              */
+                         /* checkpoints at 1.15x instead of 2x the MFMA issue of CC_DTYPE_F16 (bench default)                              */
 
 #define CC_MAX_DET 300   /* rows per frame of the detector output (detection/yolov9.py:439) */
 
