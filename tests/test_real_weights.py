@@ -61,3 +61,36 @@ def test_real_yolov9c_hip_vs_oracle():
         g = YOLOv9("c", 640, state_dict=sd, dtype=dt)(frame).numpy()
         _, _, m, _, _ = match_detections(ref, g, 0.5)
         assert m >= 0.9 * n_ref
+
+
+@pytest.mark.skipif(not (os.path.exists(YOLO_W) and os.path.isdir(IMG)), reason="real YOLOv9-C checkpoint / reference images not present")
+@pytest.mark.parametrize("dtype", ["f16h", "f16s"])
+def test_real_yolov9c_tolerance_modes(dtype):
+    """The check DESIGN.md section 5 cannot make offline: the tolerance modes on a TRAINED float32 checkpoint and natural images, against the
+    f32 oracle, held to the bars of oracle.yolov9_oracle.tolerance_bars.  "f16s" carries every weight to ~22 bits; "f16h" keeps the second plane only in the
+    stem and the backbone's 1x1 convs and relies on controlled rounding for the 3x3 convs - measured on synthetic checkpoints only."""
+    import torch
+    from clearcam_amd.weights import load_safetensors
+    from clearcam_amd.yolov9 import YOLOv9
+    from oracle.yolov9_oracle import YOLOv9Oracle, decoded_rows, parity_summary
+    sd = load_safetensors(YOLO_W)
+    o = YOLOv9Oracle("c", 640, sd)
+    m = YOLOv9("c", 640, state_dict=sd, dtype=dtype)
+    n_objects = 0
+    for name in sorted(n for n in os.listdir(IMG) if n.lower().endswith((".jpg", ".jpeg", ".png"))):
+        frame = _bgr(os.path.join(IMG, name))
+        with torch.no_grad():
+            x = o.network_input(frame[None])
+            y = o.decode(o.head_raw(o.features(x)))
+            ref = o.scale_boxes(tuple(x.shape[2:]), o.postprocess(y), frame.shape[:2]).numpy()
+        got = m(frame).numpy()[None]
+        # detections in source-frame pixels, anchors in network (letterboxed) pixels: the tolerance is 1e-3 of the respective larger side
+        det = parity_summary(ref, got, 1e-3 * max(frame.shape[:2]))
+        anc = parity_summary(np.zeros_like(ref), np.zeros_like(got), 1e-3 * max(x.shape[2:]), decoded_rows(y), m.get_tensor("decoded"))
+        n = max(det["n_ref"], det["n_got"])
+        n_objects += det["n_ref"]
+        assert det["n_strict"] >= n - max(1, int(0.015 * n)), (dtype, name, det)      # a handful of objects per image: at most one row may differ
+        if anc["anchors_both_over_thr"]:
+            assert anc["anchor_box_err_px_p999"] <= anc["box_tol_px"] and anc["anchor_box_err_px_max"] <= 1.5 * anc["box_tol_px"], (dtype, name, anc)
+            assert anc["anchor_score_err_max"] <= 2e-3, (dtype, name, anc)
+    assert n_objects > 0
