@@ -21,6 +21,7 @@ Environment (tests only): CLEARCAM_BENCH_BACKEND=gloo runs the N>1 plumbing on C
 the caller has put in place (tests/test_bench_multi.py mocks them); the default is "nccl" (RCCL) on cuda:LOCAL_RANK.
 
 Rank 0 prints ONE JSON line with the contract fields plus
+  dtype         the arithmetic type of the matrix work ("f16": f16 operands, f32 accumulation); `storage_mode` names the mode ("f16h", ...)
   roofline      dominant kernel family (the conv kernels): algorithmic FLOPs per step / their summed duration per
                 step with ONE batch in flight, measured LIVE in this run (whole-step hipGraph minus non-conv hipGraph,
                 hipEvents on the launch stream); the committed rocprofv3 trace of the same kernels (digest-, device- and
@@ -717,7 +718,7 @@ def main() -> None:
                       else f"yolov9{args.size}_{fh}x{fw}_letterbox{args.res}_frames_per_sec",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": {"f16h": "f16", "f16s": "f16"}.get(args.dtype, args.dtype), "storage_mode": args.dtype, "data": "synthetic",
             "config": {"workload": f"YOLOv9-{args.size.upper()} {args.dtype} batch={B} {fh}x{fw} frames (letterbox {args.res}) per GPU, "
                                    f"uint8 BGR frames resident in HBM, seeded synthetic weights, full detect path "
                                    f"(letterbox+convs+decode+top300+NMS)",
