@@ -321,9 +321,25 @@ MATCH_16BIT = {"bf16": 0.90, "f16": 0.985, "f16s": 0.985, "f16h": 0.985}
 SCORE_16BIT = {"bf16": 1e-2, "f16": 2e-3, "f16s": 2e-3, "f16h": 2e-3}
 
 
+_CASES = {}                                            # the last two f32-oracle runs: parametrised tests share their 64-frame case
+
+
 def conditioned_case(frames, chunk=8, exact=True, emulate=(), seed=1234):
     """f32 oracle over `frames` in chunks (CPU memory): detections (B,300,6), P3/P4/P5 as NHWC arrays, decoded rows (B,A,6).
     `emulate`: storage types whose rounding emulation (oracle/lowprec_oracle.py) is run on the same frames -> {dtype: (det, dec)}."""
+    import hashlib
+    key = (frames.shape, hashlib.sha256(frames.tobytes()).hexdigest(), chunk, exact, seed)
+    if not emulate and key in _CASES:
+        return list(_CASES[key])
+    out = _conditioned_case(frames, chunk, exact, emulate, seed)
+    if not emulate:
+        while len(_CASES) >= 2:
+            _CASES.pop(next(iter(_CASES)))
+        _CASES[key] = tuple(out)
+    return out
+
+
+def _conditioned_case(frames, chunk, exact, emulate, seed):
     from clearcam_amd.weights import conditioned_yolov9_state_dict
     sd = conditioned_yolov9_state_dict("c", seed, exact=exact)        # seeds 1234, 7, 99: three independently calibrated checkpoints
     res = max(frames.shape[1:3])
