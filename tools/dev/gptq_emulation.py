@@ -27,15 +27,21 @@ oc = yo.YOLOv9Oracle("c", 640, sd); H = {}
 orig = oc._conv2d
 def hooked(x, name, stride=1, groups=1):
     w = oc.sd[name + ".weight"]
-    if name not in H and w.shape[2] == 1 and groups == 1:
-        X = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).double()
-        if X.shape[0] > 200000: X = X[torch.randperm(X.shape[0], generator=torch.Generator().manual_seed(0))[:200000]]
+    if name not in H and groups == 1 and (w.shape[2] == 1 or os.environ.get("GPTQ_3X3")):
+        k = w.shape[2]
+        if k == 1:
+            X = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+        else:
+            X = torch.nn.functional.unfold(x, k, padding=k // 2, stride=stride).permute(0, 2, 1).reshape(-1, x.shape[1] * k * k)
+        rows = 200000 if k == 1 else 40000
+        if X.shape[0] > rows: X = X[torch.randperm(X.shape[0], generator=torch.Generator().manual_seed(0))[:rows]]
+        X = X.double()
         H[name] = (X.T @ X / X.shape[0])
     return orig(x, name, stride, groups)
 oc._conv2d = hooked
 with torch.no_grad():
     oc.decode(oc.head_raw(oc.features(oc.network_input(calib))))
-print("calibrated", len(H), "1x1 convs", flush=True)
+print("calibrated", len(H), "convs", flush=True)
 def gptq(w, Hm, damp=0.01):
     """w (co, ci) f32 -> f16-representable (co, ci); column by column with error feedback through the inverse Hessian (GPTQ)."""
     Wm = w.double().clone(); ci = Wm.shape[1]
@@ -56,14 +62,14 @@ for n in names:
     w = o0.sd[n + ".weight"]
     plain[n] = emu.q_feedback(w); spl[n] = se.split_f16(w)
     if n in H:
-        gq[n] = gptq(w[:, :, 0, 0], H[n]).reshape(w.shape)
+        gq[n] = gptq(w.reshape(w.shape[0], -1), H[n]).reshape(w.shape)
         # report the layer-level proxy: expected squared output error under the calibration covariance
 print("rounded in", round(time.time() - t0), "s", flush=True)
 def proxy(n, q):
-    d = (q - o0.sd[n + ".weight"])[:, :, 0, 0].double(); return float((d @ H[n] * d).sum())
+    d = (q - o0.sd[n + ".weight"]).reshape(q.shape[0], -1).double(); return float((d @ H[n] * d).sum())
 tot_p = sum(proxy(n, plain[n]) for n in H); tot_g = sum(proxy(n, gq[n]) for n in H)
 nearest = {n: o0.sd[n + ".weight"].to(torch.float16).float() for n in H}
-print("sum over 1x1 convs of E|dW x|^2 on the calibration frames: nearest %.3e  controlled %.3e  gptq %.3e" % (sum(proxy(n, nearest[n]) for n in H), tot_p, tot_g), flush=True)
+print("sum over the calibrated convs of E|dW x|^2 on the calibration frames: nearest %.3e  controlled %.3e  gptq %.3e" % (sum(proxy(n, nearest[n]) for n in H), tot_p, tot_g), flush=True)
 blk = lambda n: int(n.split(".")[2])
 class O(LowPrecOracle):
     def __init__(self, choose):
@@ -71,8 +77,9 @@ class O(LowPrecOracle):
         for n in names: self.sd[n + ".weight"] = choose(n)
 cfgs = {
  "controlled rounding, no split": lambda n: plain[n],
- "GPTQ for 1x1 convs, no split": lambda n: gq.get(n, plain[n]),
- "GPTQ for 1x1 + stem split": lambda n: spl[n] if blk(n) == 0 else gq.get(n, plain[n]),
+ "GPTQ, no split": lambda n: gq.get(n, plain[n]),
+ "GPTQ + stem split": lambda n: spl[n] if blk(n) == 0 else gq.get(n, plain[n]),
+ "all split": lambda n: spl[n],
 }
 for name, ch in cfgs.items():
     got, dec = se.run(O(ch), frames)
