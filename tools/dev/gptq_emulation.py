@@ -1,4 +1,4 @@
-# dev tool (CPU): env CALIB = noise | smooth | blocks (calibration frames), SEED (checkpoint), NF (test frames)
+# dev tool (CPU): env CALIB = noise | smooth | blocks | lowc (calibration frames), NCAL (how many), DAMP, GPTQ_3X3, SEED (checkpoint), NF (test frames)
 # CPU study: covariance-aware (GPTQ-style) rounding of the 1x1 convs' weights to f16, calibrated on 4 noise frames; 3x3 convs keep controlled rounding
 import sys, os, numpy as np, torch, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.argv = ['x']
@@ -10,7 +10,7 @@ from oracle.lowprec_oracle import LowPrecOracle
 SEED = int(os.environ.get("SEED", "1234")); NF = int(os.environ.get("NF", "64"))
 sd = W.conditioned_yolov9_state_dict("c", SEED, exact=False)
 frames = np.random.default_rng(SEED + 1).integers(0, 256, (NF, 640, 640, 3), dtype=np.uint8)
-calib = np.random.default_rng(4242).integers(0, 256, (4, 640, 640, 3), dtype=np.uint8)
+calib = np.random.default_rng(4242).integers(0, 256, (int(os.environ.get("NCAL", "4")), 640, 640, 3), dtype=np.uint8)
 CAL = os.environ.get("CALIB", "noise")
 if CAL == "smooth":                                   # a DIFFERENT input distribution: heavily blurred noise (natural-image-like spectrum), contrast stretched
     import torch.nn.functional as F
@@ -18,8 +18,10 @@ if CAL == "smooth":                                   # a DIFFERENT input distri
     for _ in range(3): t = F.avg_pool2d(F.pad(t, (8, 8, 8, 8), mode="reflect"), 17, 1)
     t = (t - t.mean((2, 3), keepdim=True)) / t.std((2, 3), keepdim=True) * 50 + 128
     calib = t.clamp(0, 255).permute(0, 2, 3, 1).to(torch.uint8).numpy().copy()
+elif CAL == "lowc":                                   # white noise of a quarter of the contrast around mid-grey
+    calib = (128 + (calib.astype(np.int32) - 128) // 4).astype(np.uint8)
 elif CAL == "blocks":                                 # piecewise-constant 32x32 blocks of random colour
-    small = np.random.default_rng(77).integers(0, 256, (4, 20, 20, 3), dtype=np.uint8)
+    small = np.random.default_rng(77).integers(0, 256, (len(calib), 20, 20, 3), dtype=np.uint8)
     calib = np.repeat(np.repeat(small, 32, 1), 32, 2)
 print("calibration frames:", CAL, calib.shape, float(calib.std()), flush=True)
 ref, dec_ref = se.run(yo.YOLOv9Oracle("c", 640, sd), frames)
@@ -42,7 +44,7 @@ oc._conv2d = hooked
 with torch.no_grad():
     oc.decode(oc.head_raw(oc.features(oc.network_input(calib))))
 print("calibrated", len(H), "convs", flush=True)
-def gptq(w, Hm, damp=0.01):
+def gptq(w, Hm, damp=float(os.environ.get("DAMP", "0.01"))):
     """w (co, ci) f32 -> f16-representable (co, ci); column by column with error feedback through the inverse Hessian (GPTQ)."""
     Wm = w.double().clone(); ci = Wm.shape[1]
     Hd = Hm.clone(); Hd += torch.eye(ci, dtype=torch.float64) * damp * Hd.diag().mean()
