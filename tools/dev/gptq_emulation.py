@@ -35,7 +35,7 @@ def hooked(x, name, stride=1, groups=1):
             X = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
         else:
             X = torch.nn.functional.unfold(x, k, padding=k // 2, stride=stride).permute(0, 2, 1).reshape(-1, x.shape[1] * k * k)
-        rows = 200000 if k == 1 else 40000
+        rows = int(os.environ.get("ROWS", "200000")) if k == 1 else 40000
         if X.shape[0] > rows: X = X[torch.randperm(X.shape[0], generator=torch.Generator().manual_seed(0))[:rows]]
         X = X.double()
         H[name] = (X.T @ X / X.shape[0])
