@@ -121,7 +121,7 @@ struct ConvP {
   // from HBM unchanged.  Ktot = 2 ks^2 Cin.  oscale = 2^-e undoes the per-layer power-of-two scale that keeps W_lo a NORMAL f16
   // number (exact: the epilogue computes fma(acc, oscale, bias)).  split = 0: oscale is ignored (taken as 1).
   int split; float oscale;
-  int variant;                   // kernel choice: 0 auto; tests force 1 direct, 2 generic MFMA, 3 halo-resident 3x3, 4 weights-stationary 3x3, 5 single-barrier schedule with 256x256 tiles, 6 the same with 128x128 tiles, 7 eight-wave two-group 256x256 kernel, 8 wave-autonomous narrow 3x3, 9 few-tile configuration (narrow channel tiles, 3-4 LDS stages)
+  int variant;                   // kernel choice: 0 auto; tests force 1 direct, 2 generic MFMA, 3 halo-resident 3x3, 4 weights-stationary 3x3, 5 single-barrier schedule with 256x256 tiles, 6 the same with 128x128 tiles, 7 eight-wave two-group 256x256 kernel, 8 wave-autonomous narrow 3x3, 9 few-tile configuration (narrow channel tiles, 3-4 LDS stages), 10 weights-resident streaming 1x1 (conv_stream.hip)
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are per DEVICE: a launcher's one-time set-up is keyed by the current

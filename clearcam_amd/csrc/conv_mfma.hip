@@ -646,6 +646,7 @@ static void launch_k(const ConvP& p, const ConvAux& a, int mtiles, hipStream_t s
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
+  note_launch(BM == 256 ? "conv_mfma_256" : "conv_mfma_128", conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>, (long)mtiles * a.nt, 2 * BM, lds);
   hipLaunchKernelGGL((conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>), dim3(mtiles * a.nt), dim3(2 * BM), lds, stream, p, a);
 }
 
@@ -675,12 +676,15 @@ template <class T, int TS> static void launch_big(const ConvP& p, const ConvAux&
   if (once.first(once.index())) {
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<T, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
+  note_launch(TS == 256 ? "conv_big_256" : "conv_big_128", conv_big_kernel<T, TS>, (long)((M + TS - 1) / TS) * a.nt, 256, lds);
   hipLaunchKernelGGL((conv_big_kernel<T, TS>), dim3(((M + TS - 1) / TS) * a.nt), dim3(256), lds, stream, p, a);
 }
 
 void launch_conv_phase(int dt, const ConvP& p, const ConvAux& a, int M, hipStream_t stream);   // conv_phase.hip
 bool conv_wave_legal(const ConvP& p);                                                            // conv_wave.hip
 void launch_conv_wave(int dt, const ConvP& p, hipStream_t stream);
+bool conv_stream_legal(const ConvP& p);                                                          // conv_stream.hip
+void launch_conv_stream(int dt, const ConvP& p, hipStream_t stream);
 
 template <class T, bool SIMPLE> static void launch_ts(const ConvP& p, const ConvAux& a, int bn, int M, hipStream_t stream) {
   if (g_cfg[0] < 0) {
@@ -727,6 +731,7 @@ template <class T, int BN> static void launch_halo(const ConvP& p, hipStream_t s
   HaloAux a{};
   a.tx = (p.Wo + 15) / 16; a.tiles = ((p.Ho + 7) / 8) * a.tx; a.nt = (p.Cout + BN - 1) / BN;
   a.inv_tiles = 1.0f / (float)a.tiles; a.inv_tx = 1.0f / (float)a.tx;
+  note_launch("conv3x3_halo", conv3x3_halo_kernel<T, BN>, (long)p.B * a.tiles * a.nt, 256, lds);
   hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN>), dim3(p.B * a.tiles * a.nt), dim3(256), lds, stream, p, a);
 }
 
@@ -761,6 +766,7 @@ template <class T, int CIN, int COUT> static void launch_ws(const ConvP& p, hipS
   a.tx = (p.Wo + 15) / 16; a.tiles = ((p.Ho + 7) / 8) * a.tx; a.total = p.B * a.tiles;
   a.inv_tiles = 1.0f / (float)a.tiles; a.inv_tx = 1.0f / (float)a.tx;
   const int blocks_per_cu = (int)(160 * 1024 / lds);           // persistent: as many blocks as fit, each walks total/grid tiles
+  note_launch("conv3x3_ws", conv3x3_ws_kernel<T, CIN, COUT>, (long)a.total, 256, lds, std::min(a.total, cus * std::max(1, blocks_per_cu)));
   hipLaunchKernelGGL((conv3x3_ws_kernel<T, CIN, COUT>), dim3(std::min(a.total, cus * std::max(1, blocks_per_cu))), dim3(256), lds, stream, p, a);
 }
 
@@ -822,12 +828,27 @@ template <class T> static bool launch_small(const ConvP& p, int M, hipStream_t s
   return true;
 }
 
+int g_stream_override = -1;                            // cc_dev_set("stream", v): A/B inside one process (tests, tools/dev)
+
 template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
   const int M = p.B * p.Ho * p.Wo;
   if constexpr (sizeof(T) == 2) {
     // (layers the halo-resident kernel takes at any batch size keep it: its K order is (channel slab, tap), every other kernel's
     //  (tap, channel), and a frame's result must not depend on the batch it arrives in - test_batch_invariance_and_determinism)
     //  narrow 3x3 layers on a few tiles go to the weights-stationary kernel instead: 6.5-7.3 us against 8.5-10.5 at batch 1 (same K order))
+    {   // thin 1x1 layers whose roof is HBM: all weights resident in registers, pixels streamed through an LDS ring (conv_stream.hip).
+        // CLEARCAM_STREAM=0 disables; CLEARCAM_STREAM_MIN_PIX = fewest output pixels it is taken for; tests force it with variant 10.
+      static int stream_on = -1, stream_min = 0;
+      if (stream_on < 0) {
+        const char* e = getenv("CLEARCAM_STREAM"); stream_on = e ? atoi(e) : 1;
+        const char* m = getenv("CLEARCAM_STREAM_MIN_PIX"); stream_min = m ? atoi(m) : 200000;   // measured (B = 64, profiles/r05f_stream_ab.txt): 1.13-1.5x at 160x160 and 80x80, a tie at 40x40 (102 400 pixels), 0.75x at 20x20
+      }
+      const int on = g_stream_override >= 0 ? g_stream_override : stream_on;
+      if (p.variant == 10 || (p.variant == 0 && on && M >= stream_min && conv_stream_legal(p))) {
+        launch_conv_stream(TypeTag<T>::dt, p, stream);
+        return;
+      }
+    }
     const bool few_narrow = p.variant == 0 && ws_legal(p) && (long)((M + 127) / 128) * ((p.Cout + 31) / 32) <= 512;
     if (few_narrow) { launch_ws_t<T>(p, stream); CC_HIP(hipGetLastError()); return; }
     if (((p.variant == 0 && !halo_applicable(p)) || p.variant == 9 || (p.variant >= 91 && p.variant <= 93)) && launch_small<T>(p, M, stream, p.variant >= 9)) return;

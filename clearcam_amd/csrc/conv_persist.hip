@@ -542,6 +542,7 @@ template <class T, int MM, int ABL = 0> static void launch_persist_t(const ConvP
   const int cus = pd.cu_count(d);
   ConvAux b = a;
   b.ntiles = ((M + 255) / 256) * a.nt;
+  note_launch("conv_persist", conv_persist_kernel<T, MM, ABL>, (long)b.ntiles, 512, lds, std::min(b.ntiles, cus));
   hipLaunchKernelGGL((conv_persist_kernel<T, MM, ABL>), dim3(std::min(b.ntiles, cus)), dim3(512), lds, stream, p, b);
 }
 

@@ -155,6 +155,7 @@ template <class T, int CIN, int COUT, int NW> static void launch_wave(const Conv
   a.tx = (p.Wo + 15) / 16; a.tiles = ((p.Ho + 1) / 2) * a.tx; a.total = p.B * a.tiles;
   a.inv_tiles = 1.0f / (float)a.tiles; a.inv_tx = 1.0f / (float)a.tx;
   const int blocks = std::min((a.total + NW - 1) / NW, cus);
+  note_launch("conv3x3_wave", conv3x3_wave_kernel<T, CIN, COUT, NW>, (long)(a.total + NW - 1) / NW, NW * 64, lds, blocks);
   hipLaunchKernelGGL((conv3x3_wave_kernel<T, CIN, COUT, NW>), dim3(blocks), dim3(NW * 64), lds, stream, p, a);
 }
 

@@ -427,6 +427,7 @@ template <class T, int HID, bool RES, bool SPLIT = false> static void launch_csp
   const int total = p.B * p.tiles;
   // persistent: one block per CU, a multiple of 8 so that every XCD gets the same number of walkers
   const int grid = RES ? std::max(8, std::min(cus, total) & ~7) : total;
+  note_launch("csp_fused", csp_fused_kernel<T, HID, RES, SPLIT>, (long)total, 512, lds, RES ? grid : 0);
   hipLaunchKernelGGL((csp_fused_kernel<T, HID, RES, SPLIT>), dim3(grid), dim3(512), lds, stream, p);
 }
 

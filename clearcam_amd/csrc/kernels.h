@@ -5,6 +5,23 @@
 
 namespace cc {
 
+// Per-launch note for the profiler's table (cc_yolo_profile -> CLEARCAM_PROFILE_CSV): which kernel a conv took, how many tiles of work it
+// had and how many tiles the chip takes per round (resident blocks x CUs; the grid for persistent kernels).  Filled only while
+// g_note_launches is set - the occupancy query is not free.
+struct LaunchNote { const char* kernel; long tiles; long slots; };
+extern LaunchNote g_launch_note;
+extern bool g_note_launches;
+template <class K> inline void note_launch(const char* name, K kernel, long tiles, int threads, size_t lds, long persistent_grid = 0) {
+  if (!g_note_launches) return;
+  long slots = persistent_grid;
+  if (!slots) {
+    int nb = 0, dev = 0; hipDeviceProp_t pr;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), threads, lds) != hipSuccess) nb = 1;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) slots = (long)nb * pr.multiProcessorCount;
+  }
+  g_launch_note = LaunchNote{name, tiles, slots > 0 ? slots : 1};
+}
+
 // ---- convolution / GEMM (conv_mfma.hip, conv_direct.hip) --------------------------------------
 // True when the MFMA implicit-GEMM kernel can run this problem (16-byte channel alignment etc.).
 bool conv_mfma_supported(int dt, const ConvP& p);

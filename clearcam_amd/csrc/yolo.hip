@@ -1062,10 +1062,12 @@ bool streams_overlap(hipStream_t a, hipStream_t b) {
 // replaced until it overlaps with all of them; rejected streams stay alive until the end so that the runtime moves on to another
 // queue.  (Stream priority classes have queue pools of their own and would separate three slots by construction, but strict
 // priority only fills gaps: 10.7 ms per B = 64 detect step against 10.1 with three equal slots.)
+LaunchNote g_launch_note = {"", 0, 1};
+bool g_note_launches = false;
 static std::mutex g_pool_mu;
 static std::map<int, std::deque<hipStream_t>> g_pool;
-hipStream_t pool_stream_get(int device) {
-  {
+hipStream_t pool_stream_get(int device, bool fresh) {
+  if (!fresh) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto& q = g_pool[device];
     if (!q.empty()) { hipStream_t s = q.front(); q.pop_front(); return s; }
@@ -1074,25 +1076,34 @@ hipStream_t pool_stream_get(int device) {
   CC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   return s;
 }
+hipStream_t pool_stream_get(int device) { return pool_stream_get(device, false); }
 void pool_stream_put(int device, hipStream_t s) {
   if (!s) return;
-  hipStreamSynchronize(s);
+  // a stream left in capture state by a failed capture, or one whose work faulted, must not be handed to the next handle
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  const bool healthy = !capturing && hipStreamSynchronize(s) == hipSuccess;
   static const bool pooled = [] { const char* e = getenv("CLEARCAM_STREAM_POOL"); return !(e && atoi(e) == 0); }();
-  if (!pooled) { hipStreamDestroy(s); return; }          // CLEARCAM_STREAM_POOL=0: the round-3 behaviour, for A/B (tests/test_gpu_streams.py)
+  if (!pooled || !healthy) { hipStreamDestroy(s); return; }   // CLEARCAM_STREAM_POOL=0: the round-3 behaviour, for A/B (tests/test_gpu_streams.py)
   std::lock_guard<std::mutex> lk(g_pool_mu);
   g_pool[device].push_back(s);
 }
 
 void grow_slot_streams(int device, hipStream_t base, std::vector<hipStream_t>& slots, int n_extra) {
   std::vector<hipStream_t> rejected;
-  while ((int)slots.size() < n_extra) {
+  bool fresh = false;                                    // after the first rejection the pool is bypassed: what it holds next may be exactly the
+  while ((int)slots.size() < n_extra) {                  // streams an earlier call rejected for this base (they share its hardware queue)
     hipStream_t t = nullptr;
     for (int attempt = 0; attempt < 12; ++attempt) {
-      t = pool_stream_get(device);
+      t = pool_stream_get(device, fresh);
       bool ok = streams_overlap(base, t);
       for (size_t j = 0; ok && j < slots.size(); ++j) ok = streams_overlap(slots[j], t);
-      if (ok || attempt == 11) break;
-      rejected.push_back(t); t = nullptr;               // held until the end, so that the pool / the runtime moves on to another queue
+      if (ok) break;
+      if (attempt == 11) {
+        fprintf(stderr, "[clearcam] warning: no stream found that overlaps with the handle's other slots after 12 attempts: batches in flight on this slot will serialise\n");
+        break;
+      }
+      rejected.push_back(t); t = nullptr; fresh = true;   // held until the end, so that the runtime moves on to another queue
     }
     slots.push_back(t);
   }
@@ -1114,6 +1125,9 @@ namespace cc { void set_error(const std::string& m) { g_err = m; } }
   catch (const std::exception& e) { cc::set_error(e.what()); return -1; }
 
 namespace cc { extern int g_phase_flags_override; }   // conv_phase.hip
+namespace cc { extern int g_stream_flags; }           // conv_stream.hip
+namespace cc { extern int g_stream_abl; }             // conv_stream.hip
+namespace cc { extern int g_stream_override; }        // conv_mfma.hip: -1 = CLEARCAM_STREAM / default, 0 / 1 = streaming 1x1 kernel off / on
 
 extern "C" {
 
@@ -1143,7 +1157,7 @@ int cc_yolo_create(cc_yolo** h, const char* size, int res, int dtype, int device
   }
   y->stream = pool_stream_get(device);
   CC_HIP(hipEventCreate(&y->ev0)); CC_HIP(hipEventCreate(&y->ev1));
-  CC_HIP(hipHostMalloc((void**)&y->nonfinite_host, 64, hipHostMallocDefault)); *y->nonfinite_host = 0;
+  CC_HIP(hipHostMalloc((void**)&y->nonfinite_host, 64, hipHostMallocDefault)); y->nonfinite_host[0] = y->nonfinite_host[1] = 0;
   *h = y.release();
   CC_API_END
 }
@@ -1215,6 +1229,9 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
   }
   const void* fdev = frames;
   if (!frames_on_device) { CC_HIP(hipMemcpyAsync(P->frames_dev, frames, P->frames_bytes, hipMemcpyHostToDevice, s)); fdev = P->frames_dev; }
+  // the plan's non-finite counter sums over the plan's life (device-output / submitted batches are read by cc_yolo_nonfinite): a host-output
+  // call answers for ITS OWN batch only - the counter is snapshotted before the step and the difference is what this call reports
+  if (!out_on_device) CC_HIP(hipMemcpyAsync(h->nonfinite_host + 1, P->nonfinite, 4, hipMemcpyDeviceToHost, s));
   CC_HIP(hipEventRecord(h->ev0, s));
   enqueue_step(h, P, s, fdev);
   CC_HIP(hipEventRecord(h->ev1, s));
@@ -1230,9 +1247,11 @@ int cc_yolo_detect(cc_yolo* h, const void* frames, int B, int H, int W, int fram
     CC_HIP(hipMemcpyAsync(h->nonfinite_host, P->nonfinite, 4, hipMemcpyDeviceToHost, s));
     CC_HIP(hipStreamSynchronize(s));
     h->last = P;
-    if (*h->nonfinite_host) {                               // the rows are in `out` (garbage where the logits were); say why
-      const int n = *h->nonfinite_host;
-      *h->nonfinite_host = 0; CC_HIP(hipMemsetAsync(P->nonfinite, 0, 4, s));
+    if (h->nonfinite_host[0] != h->nonfinite_host[1]) {     // the rows are in `out` (garbage where the logits were); say why
+      const int n = h->nonfinite_host[0] - h->nonfinite_host[1];
+      // this batch's anchors have been reported: take them out of the running count (earlier device-output batches stay in it)
+      CC_HIP(hipMemcpyAsync(P->nonfinite, h->nonfinite_host + 1, 4, hipMemcpyHostToDevice, s)); CC_HIP(hipStreamSynchronize(s));
+      h->nonfinite_host[0] = h->nonfinite_host[1];
       throw cc::Error(-34, std::to_string(n) + " anchors with non-finite logits: activations left the storage type's range (f16 saturates at 65504) - "
                            "run this checkpoint with dtype bf16 or f32");
     }
@@ -1381,11 +1400,16 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
   std::vector<hipEvent_t> ev(2 * n);
   for (auto& e : ev) CC_HIP(hipEventCreate(&e));
   double acc[5] = {0, 0, 0, 0, 0}, macs = 0; int nconv = 0;
+  std::vector<cc::LaunchNote> notes(n, cc::LaunchNote{"", 0, 1});
   for (int it = 0; it < iters; ++it) {
     for (size_t i = 0; i < n; ++i) {
       const Op& op = P->ops[i];
       CC_HIP(hipEventRecord(ev[2 * i], s));
+      cc::g_note_launches = it == 0 && getenv("CLEARCAM_PROFILE_CSV");   // first pass only: the occupancy query sits between the events
+      cc::g_launch_note = cc::LaunchNote{"", 0, 1};
       launch_op(h->dtype, P, op, s, true);
+      if (it == 0) notes[i] = cc::g_launch_note;
+      cc::g_note_launches = false;
       CC_HIP(hipEventRecord(ev[2 * i + 1], s));
     }
     CC_HIP(hipStreamSynchronize(s));
@@ -1401,7 +1425,17 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
   if (const char* path = getenv("CLEARCAM_PROFILE_CSV")) {   // per-launch table for tuning
     FILE* f = fopen(path, "w");
     if (f) {
-      fprintf(f, "op,kind,ms,M,Cout,Ktot,ks,stride,Cin,alg_gmac,tflops,gbytes_min,gbs,weight_planes\n");
+      fprintf(f, "op,kind,ms,M,Cout,Ktot,ks,stride,Cin,alg_gmac,tflops,gbytes_min,gbs,weight_planes,kernel,tiles,slots,rounds,last_round_fill,bound,roof_ms\n");
+      // tiles / slots: units of work of the launch and how many the chip takes at once (resident blocks x CUs; the grid of a persistent kernel);
+      // rounds = ceil(tiles / slots), last_round_fill = share of the slots the last round uses; bound / roof_ms = the larger of
+      // FLOPs / 2.5 PFLOP/s and minimum bytes / 8 TB/s
+      auto tail = [&](size_t i, double macs, double bytes) {
+        const cc::LaunchNote& ln = notes[i];
+        const long rounds = ln.tiles ? (ln.tiles + ln.slots - 1) / ln.slots : 0;
+        const double fill = rounds ? (double)(ln.tiles - (rounds - 1) * ln.slots) / (double)ln.slots : 0.0;
+        const double tm = 2 * macs / 2.5e15 * 1e3, tb = bytes / 8e12 * 1e3;
+        fprintf(f, ",%s,%ld,%ld,%ld,%.3f,%s,%.4f\n", ln.kernel, ln.tiles, ln.slots, rounds, fill, tm > tb ? "mfma" : "hbm", tm > tb ? tm : tb);
+      };
       for (size_t i = 0; i < n; ++i) {
         const Op& op = P->ops[i];
         float t = 0; hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
@@ -1412,24 +1446,28 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
           const double in0 = avg ? (double)(c.Hin + 1) * (c.Win + 1) : (double)(c.Hin >> c.s0.shift) * (c.Win >> c.s0.shift);
           const double bytes = (double)c.B * in0 * c.s0.C * es + (double)c.B * (c.Hin >> c.s1.shift) * (c.Win >> c.s1.shift) * c.s1.C * es
                              + M * c.Cout * (c.out_f32 ? 4 : es) + (c.res ? M * c.Cout * es : 0) + (double)c.Cout * c.Ktot * es;
-          fprintf(f, "%zu,%s,%.4f,%.0f,%d,%d,%d,%d,%d,%.4f,%.1f,%.4f,%.0f,%d\n", i, avg ? "conv_avg" : "conv", t, M, c.Cout, c.Ktot, c.ks, c.stride, c.Cin,
+          fprintf(f, "%zu,%s,%.4f,%.0f,%d,%d,%d,%d,%d,%.4f,%.1f,%.4f,%.0f,%d", i, avg ? "conv_avg" : "conv", t, M, c.Cout, c.Ktot, c.ks, c.stride, c.Cin,
                   op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9, 1 + c.split);
+          tail(i, op.alg_macs, bytes);
         } else if (op.kind == 1) {
           const PoolP& q = op.pool; const double es = dtype_size(h->dtype);
           const double bytes = ((double)q.B * q.H * q.W + (double)q.B * q.Ho * q.Wo) * q.C * es;
-          fprintf(f, "%zu,pool%d_k%d_s%d,%.4f,%.0f,%d,0,%d,%d,%d,0,0,%.4f,%.0f,0\n", i, q.mode, q.k, q.stride, t, (double)q.B * q.Ho * q.Wo, q.C, q.k, q.stride, q.C,
+          fprintf(f, "%zu,pool%d_k%d_s%d,%.4f,%.0f,%d,0,%d,%d,%d,0,0,%.4f,%.0f,0", i, q.mode, q.k, q.stride, t, (double)q.B * q.Ho * q.Wo, q.C, q.k, q.stride, q.C,
                   bytes / 1e9, bytes / (t * 1e-3) / 1e9);
+          tail(i, 0.0, bytes);
         } else if (op.kind == 5) {
           const StemP& q = op.stem; const double M = (double)q.pre.B * q.Ho * q.Wo, es = dtype_size(h->dtype);
           const double bytes = (double)q.pre.B * q.pre.H * q.pre.W * 3 * (q.pre.frame_f32 ? 4 : 1) + M * q.Cout * es;
-          fprintf(f, "%zu,stem_fused,%.4f,%.0f,%d,27,3,2,3,%.4f,%.1f,%.4f,%.0f,%d\n", i, t, M, q.Cout, op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12,
+          fprintf(f, "%zu,stem_fused,%.4f,%.0f,%d,27,3,2,3,%.4f,%.1f,%.4f,%.0f,%d", i, t, M, q.Cout, op.alg_macs / 1e9, 2 * op.alg_macs / (t * 1e-3) / 1e12,
                   bytes / 1e9, bytes / (t * 1e-3) / 1e9, q.w_lo ? 2 : 1);
+          tail(i, op.alg_macs, bytes);
         } else if (op.kind == 6) {
           const CspP& q = op.csp; const double M = (double)q.B * q.H * q.W, es = dtype_size(h->dtype);
           const double bytes = M * 4 * q.hid * es + (double)(8 + 18) * q.hid * q.hid * es;     // x in, out out, the four weight matrices
-          fprintf(f, "%zu,csp_fused,%.4f,%.0f,%d,%d,3,1,%d,%.4f,%.1f,%.4f,%.0f,%d\n", i, t, M, 2 * q.hid, (8 + 18) * q.hid, 2 * q.hid, op.alg_macs / 1e9,
+          fprintf(f, "%zu,csp_fused,%.4f,%.0f,%d,%d,3,1,%d,%.4f,%.1f,%.4f,%.0f,%d", i, t, M, 2 * q.hid, (8 + 18) * q.hid, 2 * q.hid, op.alg_macs / 1e9,
                   2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9, 1 + q.split);
-        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : (op.kind == 7 ? "head_tail" : "topk_nms")), t);
+          tail(i, op.alg_macs, bytes);
+        } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0,0,,0,0,0,0,,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : (op.kind == 7 ? "head_tail" : "topk_nms")), t);
       }
       fclose(f);
     }
@@ -1554,6 +1592,9 @@ int cc_dev_set(const char* key, int value) {
   CC_API_BEGIN
   CC_CHECK(key, "null key");
   if (std::string(key) == "phase_flags") cc::g_phase_flags_override = value;
+  else if (std::string(key) == "stream") cc::g_stream_override = value;
+  else if (std::string(key) == "stream_abl") cc::g_stream_abl = value;
+  else if (std::string(key) == "stream_flags") cc::g_stream_flags = value;
   else throw cc::Error(-22, std::string("cc_dev_set: unknown key ") + key);
   CC_API_END
 }

@@ -18,6 +18,7 @@ No collective anywhere: cameras are independent.  There is no C
 from __future__ import annotations
 
 import os
+import weakref
 import time
 from typing import Dict, List, Optional, Sequence
 
@@ -130,7 +131,7 @@ class StreamPipeline:
         # ticket counter, which would invalidate the tickets another live pipeline holds (same depth: cc_yolo_set_in_flight is a no-op)
         users = getattr(model, "_pipelines", None)
         if users is None:
-            users = model._pipelines = set()
+            users = model._pipelines = weakref.WeakSet()   # a pipeline dropped without close() must not pin its slots or block another depth
         if self.in_flight:
             if any(p.in_flight and p.depth != depth for p in users):
                 raise RuntimeError("this model already serves a pipeline with another number of detector slots: close() that pipeline first")
@@ -307,7 +308,7 @@ def main() -> None:
     a = ap.parse_args()
     model = YOLOv9(a.size, a.res, state_dict=shift_class_bias(synthetic_yolov9_state_dict(a.size, 1234), a.cls_bias_shift), dtype=a.dtype)
     pipe = StreamPipeline(model, a.cams, (a.height, a.width), depth=a.depth, det_thresh=a.thresh, in_flight=None if a.in_flight is None else bool(a.in_flight))
-    cams = None if a.resident else make_cameras(a.cams, a.height, a.width)
+    cams = None if a.resident else make_cameras(a.cams, a.height, a.width, ring=pipe.depth + 1)   # a frame stays the source of an upload for `depth` ticks
     print(json.dumps(pipe.run(cams, a.batches)))
 
 

@@ -100,7 +100,8 @@ void cc_yolo_destroy(cc_yolo* h);
  * x (B,H,W,Cin) and out (B,Ho,Wo,Cout) in storage dtype `dtype`; w OIHW float32 host, bias host.
  * groups>1 is densified to block-diagonal weights exactly as the detector does for the head convs.
  * force_direct selects the kernel: 0 = what the detector would pick, 1 = direct (non-MFMA) fallback, 2 = generic MFMA
- * implicit GEMM, 3 = halo-resident 3x3, 4 = weights-stationary 3x3 (3 and 4 fail if the shape is not eligible). */
+ * implicit GEMM, 3 = halo-resident 3x3, 4 = weights-stationary 3x3, ... 10 = weights-resident streaming 1x1 (ConvP::variant in
+ * csrc/common.h lists them all; the specialised ones fail if the shape is not eligible). */
 int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, const float* w_oihw,
                    const float* bias, int Cout, int k, int stride, int groups, int act, void* out_dev,
                    int force_direct, void* stream);
@@ -116,7 +117,8 @@ int cc_attn_bench(int dtype, int B, int L, int H, int causal, int abl, int iters
  * first moments over the taps stay within about an ulp of their float32 values.  out[i] = the value the storage type holds, as float32. */
 int cc_round_weights(int dtype, const float* w, int64_t cout, int64_t cin, int64_t k, float* out);
 /* Diagnostic (kernel tuning): set a process-wide tuning switch at run time so that one process can A/B kernel variants.
- * key "phase_flags": the CLEARCAM_PHASE_FLAGS bit set of the eight-wave kernel (-1 = back to the environment / default).
+ * key "phase_flags": the CLEARCAM_PHASE_FLAGS bit set of the eight-wave kernel (-1 = back to the environment / default);
+ * key "stream": the weights-resident streaming 1x1 kernel off (0) / on (1) / as CLEARCAM_STREAM says (-1).
  * Plans already built keep the launches they were built with.  Not part of the drop-in surface. */
 int cc_dev_set(const char* key, int value);
 

@@ -196,6 +196,67 @@ def test_split_weight_conv_matches_torch(case):
         assert torch.equal(got, conv_hip(x, w, b, stride, groups, 0, "f16s", force_direct=2))
 
 
+# (name, B, Cin, H, W, Cout): the weights-resident streaming 1x1 kernel (conv_stream.hip, variant 10), every instantiated shape
+STREAM_CASES = [
+    ("256_256", 2, 256, 40, 40, 256),                     # 50 tiles of 64 pixels
+    ("256_256_long", 16, 256, 80, 80, 256),               # 1600 tiles: several per block, the steady-state counted waits
+    ("256_256_ragged", 1, 256, 13, 21, 256),              # M = 273: ragged last tile, fewer tiles than ring slots per block
+    ("512_256", 2, 512, 40, 40, 256),                     # 32-pixel tiles (plain modes only: two planes would need K = 1024)
+    ("128_128", 3, 128, 40, 40, 128),
+    ("128_128_ragged", 1, 128, 7, 9, 128),                # M = 63: one partial tile
+    ("64_64", 2, 64, 80, 80, 64),
+    ("64_64_long", 64, 64, 80, 80, 64),                   # 1600 tiles of 256 pixels
+    ("64_64_ragged", 1, 64, 33, 17, 64),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f16s"])
+@pytest.mark.parametrize("act", [1, 0])
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
+def test_stream_1x1_equals_generic(case, act, dtype):
+    """Variant 10 (all weights in registers, pixels streamed through an LDS ring, counted vmcnt over DMA pieces and stores) against torch and,
+    bit for bit, against the generic tile kernel: same MFMA, same chunk -> k mapping, same (plane, channel) walk, same epilogue."""
+    _, B, Cin, H, W_, Cout = case
+    if dtype == "f16s" and Cin == 512:
+        pytest.skip("two planes of 512 channels exceed the register-resident weight budget: not an instantiated shape")
+    g = torch.Generator().manual_seed(hash(case[0]) % 1000 + act)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    got = conv_hip(x, w, b, 1, 1, act, dtype, force_direct=10)
+    generic = conv_hip(x, w, b, 1, 1, act, dtype, force_direct=2)
+    assert torch.equal(got, generic)
+    if dtype == "f16s":
+        ref = F.conv2d(x.half().float(), split_value(w), b)
+        tol = 1e-3
+    else:
+        ref = F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b)
+        tol = TOL[dtype]
+    if act:
+        ref = F.silu(ref)
+    assert float((got - ref).abs().max() / ref.abs().max()) <= tol
+
+
+def test_detect_same_bits_with_and_without_stream_kernel():
+    """The detector with the streaming 1x1 kernel on (default) and off (cc_dev_set("stream", 0)): identical rows in every storage mode -
+    the kernel reads channel-slice views of the Concat buffers there, which the single-layer entry does not exercise."""
+    from clearcam_amd.weights import conditioned_yolov9_state_dict
+    L = _lib.lib()
+    sd = conditioned_yolov9_state_dict("c", 1234)
+    frames = np.random.default_rng(5).integers(0, 256, (16, 480, 640, 3), dtype=np.uint8)
+    for dtype in ("f16h", "f16s", "bf16"):
+        outs = []
+        for on in (1, 0):
+            _lib.check(L.cc_dev_set(b"stream", on))
+            try:
+                m = _yolo("c", 640, sd, dtype)
+                outs.append(np.array(m.detect_batch(frames)))
+                del m
+            finally:
+                _lib.check(L.cc_dev_set(b"stream", -1))
+        assert np.array_equal(outs[0], outs[1]), dtype
+
+
 def test_specialised_kernels_refuse_ineligible_shapes():
     from clearcam_amd._lib import CCError
     x, w, b = torch.randn(1, 128, 16, 16), torch.randn(64, 128, 3, 3), torch.zeros(64)
@@ -478,6 +539,43 @@ def test_tolerance_modes_on_other_checkpoints(seed):
         s = check_16bit_against_oracle(m, dtype, frames, ref, feats, dec_ref, min_dets=250)
         print(f"checkpoint seed {seed}, {dtype}: {s}")
         m.close()
+
+
+def test_conditioned_checkpoint_f32_mode():
+    """The conditioned checkpoint through the f32 parity mode: the tight f32 bars hold on it too (restored in round 5: the 16-bit
+    tolerance modes are judged against the oracle, and this pins the library's own f32 mode to the same oracle on the same network)."""
+    frames = noise_frames(3, 8, 640, 640)
+    sd, ref, feats, _ = conditioned_case(frames)
+    m = _yolo("c", 640, sd, "f32")
+    got = m.detect_batch(frames)
+    for name, r in zip(("p3", "p4", "p5"), feats):
+        assert np.sqrt(((m.get_tensor(name) - r) ** 2).mean() / (r ** 2).mean()) < 2e-4, name
+    tot = [0, 0, 0]
+    for b in range(8):
+        a, c, k, be, se = yo.match_detections(ref[b], got[b], 0.9)
+        tot[0] += a; tot[1] += c; tot[2] += k
+        assert be <= 0.64 and se <= 1e-3, (be, se)
+    assert tot[0] > 50 and tot[2] >= 0.99 * max(tot[0], tot[1]) - 1, tot
+
+
+@pytest.mark.parametrize("dtype,min_match,feat_rel", [("f16", 0.85, 0.08), ("f16h", 0.85, 0.08), ("f16s", 0.85, 0.08), ("bf16", 0.55, 0.5)])
+def test_detect_16bit_modes_on_the_chaotic_checkpoint(dtype, min_match, feat_rel, sd_c):
+    """The chaotic seeded checkpoint (perturbation gain 30-60x, clearcam_amd/assets/synth_cond_report.json) amplifies storage rounding: no
+    16-bit mode can hold the tolerance bars on it (INTEGRATION.md says so); this guards against gross breakage there - finite rows, features
+    within a loose relative bar, most detections found - for every 16-bit mode including the default.  The tight bars are the tests above."""
+    frames = noise_frames(1, 2, 640, 640)
+    o = yo.YOLOv9Oracle("c", 640, sd_c)
+    ref = o.detect_batch(frames)
+    with torch.no_grad():
+        p3 = o.block_outputs[15].permute(0, 2, 3, 1).numpy()
+    m = _yolo("c", 640, sd_c, dtype)
+    got = m.detect_batch(frames)
+    rel = np.sqrt(((m.get_tensor("p3") - p3) ** 2).mean() / (p3 ** 2).mean())
+    assert rel < feat_rel, rel
+    for b in range(2):
+        n_ref, n_got, n_match, _, _ = yo.match_detections(ref[b], got[b], 0.5)
+        assert n_match >= min_match * n_ref and abs(n_got - n_ref) <= 0.15 * n_ref, (n_ref, n_got, n_match)
+    assert np.isfinite(got).all()
 
 
 def test_backbone_split_boundary(monkeypatch, sd_t):
