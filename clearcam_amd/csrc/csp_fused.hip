@@ -41,11 +41,14 @@ template <int V> using IC = std::integral_constant<int, V>;
 template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(IC<I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-// SPLIT: every weight matrix is two f16 planes (ConvP::split; rows [tap: hi(Cin) | lo(Cin)]): twice the weight slabs, the same x / a / t /
+// SPLIT 1: every weight matrix is two f16 planes (ConvP::split; rows [tap: hi(Cin) | lo(Cin)]): twice the weight slabs, the same x / a / t /
 // u / b fragments walked once per plane, in the conv kernels' order (tap, plane, channel) - still bit-identical to the launches it replaces.
-template <int HID, bool SPLIT = false> struct CspGeom {
+// SPLIT 2 (round 5): two planes in the 1x1 convs only (cv1 | cv2 and cv3), one in the two 3x3 convs - what dtype "f16h" gives the backbone's
+// RepNCSP blocks, which had to run as four launches while the kernel took one flag for all four convs.
+template <int HID, int SPLIT = 0> struct CspGeom {
+  static constexpr bool SPLIT1 = SPLIT != 0, SPLIT3 = SPLIT == 1;            // two planes in the 1x1 convs / in the 3x3 convs
   static constexpr int C2 = 2 * HID, NSLAB = C2 / 64;                        // X / cv1|cv2 / cv3 K slabs of 64 channels
-  static constexpr int NSLABW = NSLAB * (SPLIT ? 2 : 1);                     // weight slabs of cv1|cv2 / cv3: [hi slabs | lo slabs]
+  static constexpr int NSLABW = NSLAB * (SPLIT1 ? 2 : 1);                     // weight slabs of cv1|cv2 / cv3: [hi slabs | lo slabs]
   static constexpr int TH = 8, TW = 16, PW = TW + 4, PH = TH + 4, PR = PH * PW;   // 12 x 20 = 240 patch pixels
   static constexpr int QW = TW + 2, QH = TH + 2, QR = QH * QW;               // 10 x 18 = 180 ring pixels
   static constexpr int CPA = HID / 8;                                        // 16-byte chunks per row of A, B, T, U
@@ -61,7 +64,7 @@ template <int HID, bool SPLIT = false> struct CspGeom {
   static constexpr int BIAS_BYTES = (2 * C2 + 2 * HID) * 4;                  // b12 | br | bb | b3 as f32
   static constexpr int SPC = HID == 64 ? 2 : 3;                              // streaming: 3x3 weight slabs per chunk
   // slabs / chunks per 3x3 stage: 9 / 5 (HID 64) and 5 / 2 (HID 32); split: a tap is [hi | lo] = two slabs at HID 64 (18 / 9), one at HID 32 (9 / 3)
-  static constexpr int NS3 = SPLIT ? (HID == 64 ? 18 : 9) : (9 * HID + 63) / 64, NC3 = (NS3 + SPC - 1) / SPC;
+  static constexpr int NS3 = SPLIT3 ? (HID == 64 ? 18 : 9) : (9 * HID + 63) / 64, NC3 = (NS3 + SPC - 1) / SPC;
   static constexpr int SLAB_BIG = C2 * 128, SLAB_SMALL = HID * 128;          // bytes of a 64-wide K slab of cv1|cv2 / cv3 and of a 3x3
   static constexpr int RING = SLAB_BIG > SPC * SLAB_SMALL ? SLAB_BIG : SPC * SLAB_SMALL;
   static constexpr int NCHUNK = 2 * NSLABW + 2 * NC3;
@@ -77,12 +80,13 @@ template <int HID, bool SPLIT = false> struct CspGeom {
   static_assert(T_BYTES + U_BYTES <= X_BYTES, "T and U alias the input patch");
 };
 
-template <class T, int HID, bool RES, bool SPLIT = false>
+template <class T, int HID, bool RES, int SPLIT = 0>
 __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
   using G = CspGeom<HID, SPLIT>;
+  constexpr bool SPLIT1 = G::SPLIT1, SPLIT3 = G::SPLIT3;
   static_assert(!(RES && SPLIT), "split weights stream (two planes do not fit beside two patches)");
   constexpr int C2 = G::C2, NSLAB = G::NSLAB, NSLABW = G::NSLABW, PW = G::PW, PR = G::PR, QW = G::QW, QR = G::QR, CPA = G::CPA, PA = G::PA;
-  const float os12 = SPLIT ? p.os12 : 1.0f, osr = SPLIT ? p.osr : 1.0f, osb = SPLIT ? p.osb : 1.0f, os3 = SPLIT ? p.os3 : 1.0f;   // exact 2^-e output scales
+  const float os12 = SPLIT1 ? p.os12 : 1.0f, osr = SPLIT3 ? p.osr : 1.0f, osb = SPLIT3 ? p.osb : 1.0f, os3 = SPLIT1 ? p.os3 : 1.0f;   // exact 2^-e output scales
   constexpr int NJ1 = C2 / 16, NJ2 = HID / 32, SPC = G::SPC, NS3 = G::NS3, NC3 = G::NC3;
   constexpr int OFF_A = RES ? G::R_OFF_A : G::S_OFF_A, OFF_B = RES ? G::R_OFF_B : G::S_OFF_B, OFF_BIAS = RES ? G::R_OFF_BIAS : G::S_OFF_BIAS;
   constexpr int BI_12 = OFF_BIAS, BI_R = BI_12 + C2 * 4, BI_B = BI_R + HID * 4, BI_3 = BI_B + HID * 4;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
     for (int kh = 0; kh < 2; ++kh) {
       // a 64-wide K slab is one tap (HID 64) or two (HID 32); split: [hi | lo] of one tap (HID 32: the k halves read the SAME 32
       // channels against the two planes) or one plane of one tap (HID 64: two slabs per tap)
-      const int tap = SPLIT ? (HID == 64 ? J / 2 : J) : (HID == 64 ? J : 2 * J + kh);
+      const int tap = SPLIT3 ? (HID == 64 ? J / 2 : J) : (HID == 64 ? J : 2 * J + kh);
       if (tap < 9) {
         const int r = tap / 3, s = tap - r * 3;
         uint4 xf[NPX], wf[NJ];
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
 
 bool csp_fused_supported(int dt, int hid, int split) { return (dt == F16 || (dt == BF16 && !split)) && (hid == 32 || hid == 64); }
 
-template <class T, int HID, bool RES, bool SPLIT = false> static void launch_csp(const CspP& p, hipStream_t stream) {
+template <class T, int HID, bool RES, int SPLIT = 0> static void launch_csp(const CspP& p, hipStream_t stream) {
   constexpr int lds = RES ? CspGeom<HID, SPLIT>::R_LDS_BYTES : CspGeom<HID, SPLIT>::S_LDS_BYTES;
   static PerDevice pd;                                 // attribute and CU count per device ordinal (common.h)
   const int pdi = pd.index();
@@ -435,15 +439,19 @@ void launch_csp_fused(int dt, const CspP& p0, hipStream_t stream) {
   CC_CHECK(csp_fused_supported(dt, p0.hid, p0.split), "fused RepNCSP: 16-bit storage (split weights: f16) and hidden width 32 or 64 only");
   CC_CHECK(p0.x_cstride % 8 == 0 && p0.x_coff % 8 == 0 && p0.out_cstride % 8 == 0 && p0.out_coff % 8 == 0 && (((uintptr_t)p0.x | (uintptr_t)p0.out) & 15) == 0,
            "fused RepNCSP: views must be 16-byte aligned");
-  CC_CHECK(p0.kw12 % 64 == 0 && p0.kw3 % 64 == 0 && p0.kwr % 64 == 0 && p0.kwb % 64 == 0 && p0.kwr >= 9 * p0.hid * (1 + p0.split) && p0.kwb >= 9 * p0.hid * (1 + p0.split) &&
-           p0.kw12 >= 2 * p0.hid * (1 + p0.split) && p0.kw3 >= 2 * p0.hid * (1 + p0.split), "fused RepNCSP: weight rows must cover whole K slabs");
+  CC_CHECK(p0.split >= 0 && p0.split <= 2, "fused RepNCSP: split is 0 (one plane), 1 (two planes everywhere) or 2 (two planes in the 1x1 convs)");
+  const int s1 = p0.split != 0, s3 = p0.split == 1;
+  CC_CHECK(p0.kw12 % 64 == 0 && p0.kw3 % 64 == 0 && p0.kwr % 64 == 0 && p0.kwb % 64 == 0 && p0.kwr >= 9 * p0.hid * (1 + s3) && p0.kwb >= 9 * p0.hid * (1 + s3) &&
+           p0.kw12 >= 2 * p0.hid * (1 + s1) && p0.kw3 >= 2 * p0.hid * (1 + s1), "fused RepNCSP: weight rows must cover whole K slabs");
   CspP p = p0;
   p.tx = (p.W + 15) / 16; p.tiles = ((p.H + 7) / 8) * p.tx;
   p.inv_tiles = 1.0f / (float)p.tiles; p.inv_tx = 1.0f / (float)p.tx;
   CC_CHECK((long)p.B * p.tiles < (1L << 22), "fused RepNCSP: too many tiles");
   const bool res = p.hid == 32 && !p.stream;                        // 56 KB of weights stay in LDS; 208 KB (hidden 64) cannot
-  if (p.split) {                                                    // two weight planes: streamed at both widths
-    if (p.hid == 64) launch_csp<f16_t, 64, false, true>(p, stream); else launch_csp<f16_t, 32, false, true>(p, stream);
+  if (p.split == 1) {                                               // two weight planes: streamed at both widths
+    if (p.hid == 64) launch_csp<f16_t, 64, false, 1>(p, stream); else launch_csp<f16_t, 32, false, 1>(p, stream);
+  } else if (p.split == 2) {                                        // ... in the 1x1 convs only (72 KB of weights at hidden 32: streamed as well)
+    if (p.hid == 64) launch_csp<f16_t, 64, false, 2>(p, stream); else launch_csp<f16_t, 32, false, 2>(p, stream);
   } else if (dt == F16) {
     if (p.hid == 64) launch_csp<f16_t, 64, false>(p, stream);
     else if (res) launch_csp<f16_t, 32, true>(p, stream); else launch_csp<f16_t, 32, false>(p, stream);

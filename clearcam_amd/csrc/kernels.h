@@ -45,7 +45,7 @@ struct CspP {
   const void* wb; int kwb; const float* bb;      // m.0.cv2: [hid][kwb]
   const void* w3; int kw3; const float* b3;      // cv3: [2*hid][kw3], k = [m-branch | cv2]
   int B, H, W, hid;
-  int split; float os12, osr, osb, os3;          // split weights (ConvP::split): rows [tap: hi | lo], the four exact 2^-e output scales
+  int split; float os12, osr, osb, os3;          // split weights (ConvP::split): 0 none, 1 all four convs, 2 the 1x1 convs (cv1 | cv2, cv3) only; rows [tap: hi | lo], the four exact 2^-e output scales
   int tx, tiles; float inv_tiles, inv_tx;        // filled by the launcher: 8x16 tiles per row / per image
   int dbg;                                       // development: 1..3 = stop after that stage and write its intermediate to `out`
   int stream;                                    // 1: take the weight-streaming one-tile-per-block variant even where the weights fit in LDS

@@ -457,10 +457,10 @@ struct Builder {
     const char* only = dev_env("CLEARCAM_CSP_ONLY");                // development: fuse just this block (csp_debug.py)
     if (only && atoi(only) != index) return false;
     if (!(a.rep_n == 1 && csp_fused_supported(Y->dtype, hid, Y->wsplit) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0)) return false;
-    // the fused kernel takes ONE split flag for its four convs; in "f16h" the 1x1 convs of a backbone RepNCSP carry two planes and its
-    // 3x3 convs one: those blocks run as four launches
-    const int s0 = pconv({r + ".cv1.conv", r + ".cv2.conv"}, {1, 1}).split;
-    return pconv({r + ".m.list.0.cv1.conv"}, {1}).split == s0 && pconv({r + ".m.list.0.cv2.conv"}, {1}).split == s0 && pconv({r + ".cv3.conv"}, {1}).split == s0;
+    // the fused kernel knows three split patterns: none, all four convs ("f16s"), the two 1x1 launches only ("f16h" in the backbone)
+    const int s12 = pconv({r + ".cv1.conv", r + ".cv2.conv"}, {1, 1}).split, s3 = pconv({r + ".cv3.conv"}, {1}).split;
+    const int sr = pconv({r + ".m.list.0.cv1.conv"}, {1}).split, sb = pconv({r + ".m.list.0.cv2.conv"}, {1}).split;
+    return s12 == s3 && sr == sb && (sr == s12 || (s12 && !sr));
   }
   void csp_fused(const std::string& r, View in, View out, int hid) {
     Op op{}; op.kind = 6; CspP& q = op.csp;
@@ -476,7 +476,7 @@ struct Builder {
     q.w12 = c12.w; q.kw12 = c12.kw; q.b12 = c12.bias; q.wr = cr.w; q.kwr = cr.kw; q.br = cr.bias;
     q.wb = cb.w; q.kwb = cb.kw; q.bb = cb.bias; q.w3 = c3.w; q.kw3 = c3.kw; q.b3 = c3.bias;
     q.B = P->B; q.H = ib.H; q.W = ib.W; q.hid = hid;
-    q.split = c12.split; q.os12 = c12.oscale; q.osr = cr.oscale; q.osb = cb.oscale; q.os3 = c3.oscale;
+    q.split = !c12.split ? 0 : (cr.split ? 1 : 2); q.os12 = c12.oscale; q.osr = cr.oscale; q.osb = cb.oscale; q.os3 = c3.oscale;
     { const char* e = dev_env("CLEARCAM_CSP_DBG"); q.dbg = e ? atoi(e) : 0; }       // stops the kernel after stage 1-3: WRONG outputs
     { const char* e = dev_env("CLEARCAM_CSP_STREAM"); q.stream = e ? atoi(e) : 0; }
     op.alg_macs = (double)P->B * ib.H * ib.W * (c12.macs_px + cr.macs_px + cb.macs_px + c3.macs_px);
@@ -1465,7 +1465,7 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
           const CspP& q = op.csp; const double M = (double)q.B * q.H * q.W, es = dtype_size(h->dtype);
           const double bytes = M * 4 * q.hid * es + (double)(8 + 18) * q.hid * q.hid * es;     // x in, out out, the four weight matrices
           fprintf(f, "%zu,csp_fused,%.4f,%.0f,%d,%d,3,1,%d,%.4f,%.1f,%.4f,%.0f,%d", i, t, M, 2 * q.hid, (8 + 18) * q.hid, 2 * q.hid, op.alg_macs / 1e9,
-                  2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9, 1 + q.split);
+                  2 * op.alg_macs / (t * 1e-3) / 1e12, bytes / 1e9, bytes / (t * 1e-3) / 1e9, q.split ? 2 : 1);
           tail(i, op.alg_macs, bytes);
         } else fprintf(f, "%zu,%s,%.4f,0,0,0,0,0,0,0,0,0,0,0,,0,0,0,0,,0\n", i, op.kind == 2 ? "decode" : (op.kind == 4 ? "cbfuse" : (op.kind == 7 ? "head_tail" : "topk_nms")), t);
       }

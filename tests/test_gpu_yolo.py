@@ -864,6 +864,8 @@ np.savez(out, **d)
     ("m", 320, "f16", 320, 320, 2, "1", 2),       # YOLOv9-m: one bottleneck per RepNCSP, hidden width 32 at 80x80
     ("c", 640, "f16s", 640, 640, 1, "2", 6),      # split weights: both widths stream their two planes (tap, plane, channel order)
     ("c", 608, "f16s", 608, 608, 2, "2", 6),      # ... ragged tiles
+    ("c", 640, "f16h", 640, 640, 1, "2", 6),      # round 5: two planes in the 1x1 convs only (the four backbone blocks), one plane everywhere (the two neck blocks)
+    ("c", 608, "f16h", 608, 608, 2, "2", 6),      # ... ragged tiles
 ])
 def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fused):
     """csp_fused_kernel (cv1|cv2, RepConvN 3x3, 3x3 + shortcut, cv3 of a RepNCSP in one launch, intermediates in LDS) against the
