@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libclearcam_hip.so")
 # every symbol include/clearcam_hip.h declares
 SYMBOLS = [
     "cc_last_error", "cc_version", "cc_device_count",
-    "cc_yolo_create", "cc_yolo_load", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_set_in_flight", "cc_yolo_submit", "cc_yolo_wait",
+    "cc_yolo_create", "cc_yolo_load", "cc_yolo_calibrate", "cc_yolo_calibration_info", "cc_gptq_round_f16", "cc_yolo_finalize", "cc_yolo_detect", "cc_yolo_set_in_flight", "cc_yolo_submit", "cc_yolo_wait",
     "cc_yolo_get_tensor", "cc_yolo_nonfinite",
     "cc_yolo_last_gpu_ms", "cc_yolo_profile", "cc_yolo_profile_graph", "cc_yolo_destroy", "cc_conv2d_nhwc", "cc_conv_bench", "cc_dev_set", "cc_round_weights", "cc_attn_bench",
     "cc_clip_create", "cc_clip_load", "cc_clip_finalize", "cc_clip_encode_image", "cc_clip_encode_text",
@@ -59,6 +59,9 @@ def lib() -> C.CDLL:
         "cc_yolo_create": [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int],
         "cc_yolo_load": [vp, C.c_char_p, vp, i64p, C.c_int],
         "cc_yolo_finalize": [vp],
+        "cc_yolo_calibrate": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int],
+        "cc_yolo_calibration_info": [vp, ip, ip],
+        "cc_gptq_round_f16": [vp, C.c_int64, C.c_int64, vp, C.c_double, vp],
         "cc_yolo_detect": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp],
         "cc_yolo_set_in_flight": [vp, C.c_int],
         "cc_yolo_submit": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_longlong)],

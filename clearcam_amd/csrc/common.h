@@ -18,7 +18,11 @@ constexpr int F16S = 3;
 // every other conv carries one f16 plane with controlled rounding, which balances a 3x3 filter's nine taps against each other and has
 // nothing to balance in a 1x1 ("Which layers need the low plane").
 constexpr int F16H = 4;
-inline int storage_dtype(int dt) { return dt == F16S || dt == F16H ? (int)F16 : dt; }
+// C-ABI dtype 5 ("f16c", round 5): ONE f16 plane everywhere except the stem conv (two planes), the 1x1 convs' weights rounded with the
+// errors steered by the second moments of their own inputs on a few calibration frames (calibrate.hip; cc_yolo_calibrate): the frame rate of
+// plain f16, the tolerance of "f16h" on inputs like the calibration frames.
+constexpr int F16C = 5;
+inline int storage_dtype(int dt) { return dt == F16S || dt == F16H || dt == F16C ? (int)F16 : dt; }
 
 inline size_t dtype_size(int dt) { return dt == F32 ? 4 : 2; }
 

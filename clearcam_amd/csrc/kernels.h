@@ -53,6 +53,14 @@ struct CspP {
 bool csp_fused_supported(int dt, int hid, int split = 0);
 void launch_csp_fused(int dt, const CspP& p, hipStream_t stream);
 
+// ---- calibration-aware rounding of the 1x1 convs (calibrate.hip, C-ABI dtype "f16c") -----------------------------------------------
+// S pixel rows (indices rows_dev) of a 1x1 stride-1 conv's input view over f32 activations -> dense (S, Cin) f32
+void launch_sample_rows(const ConvP& p, const int* rows_dev, int S, float* out_dev, hipStream_t stream);
+// H (ci x ci) = X^T X / rows in double
+void second_moments(const float* X, int rows, int ci, std::vector<double>& H);
+// GPTQ column walk: w (co x ci) f32 -> f16-representable f32 values; 0 ok, < 0: H not positive definite (leave the conv to controlled rounding)
+int gptq_round_f16(const float* w, int co, int ci, const double* H, double damp, float* out);
+
 // ---- pooling (pool.hip) ------------------------------------------------------------------------
 struct PoolP {
   const void* in; int in_cstride, in_coff;

@@ -25,18 +25,21 @@ from .weights import load_safetensors
 # 3x3 filter's taps and has nothing to balance in a 1x1) - and stays as close to the f32 oracle on three independently calibrated
 # un-rounded checkpoints at 1.4x the frame rate.  Plain f16 / bf16 round every weight
 # to 11 / 8 bits: speed modes.  "f32" is the exact-arithmetic parity mode.
-DTYPES = {"f32": 0, "float32": 0, "f16": 1, "float16": 1, "half": 1, "bf16": 2, "bfloat16": 2, "f16s": 3, "f16_split": 3, "f16h": 4}
+DTYPES = {"f32": 0, "float32": 0, "f16": 1, "float16": 1, "half": 1, "bf16": 2, "bfloat16": 2, "f16s": 3, "f16_split": 3, "f16h": 4, "f16c": 5}
 MAX_DET = 300
 
 
 class YOLOv9:
     def __init__(self, size: str = "t", res: int = 1280, state_dict: Optional[Dict[str, np.ndarray]] = None,
-                 weights: Optional[str] = None, dtype: str = "f16h", device: int = 0):
+                 weights: Optional[str] = None, dtype: str = "f16h", device: int = 0, calibration_frames=None):
         """dtype: "f16h" (default) - f16 activations, split f16 weights in the backbone's 1x1 convs and the stem, one controlled-rounded
         f16 plane elsewhere: detections within the reference tolerance on un-rounded float32 checkpoints; "f16s" - split weights in every
         conv (weights exact to f32 whatever the checkpoint; 0.7x the rate); "f32" - the exact-arithmetic parity mode (5x slower); "f16" / "bf16" - speed modes whose 11 / 8-bit weight
         rounding (controlled rounding: filter sums preserved) moves boxes by up to a pixel / several pixels on the conditioned synthetic checkpoint.  f16
-        storage saturates at 65504: a checkpoint whose activations exceed that needs "bf16" or "f32"."""
+        storage saturates at 65504: a checkpoint whose activations exceed that needs "bf16" or "f32".
+        "f16c" (round 5) - one f16 plane per conv (two in the stem conv) at plain f16's rate, the 1x1 convs' weights rounded by a
+        calibration-aware recursion on `calibration_frames` ((B,H,W,3) BGR uint8 / float32 array: a few frames of the camera; default: four
+        frames of seeded white noise) - "f16h"'s tolerance on inputs like the calibration frames."""
         if size not in YOLO_ARCH and size != "e":
             raise ValueError(f"unsupported size {size!r}: t, s, m, c, e")
         self.size, self.res, self.dtype, self.device = size, res, dtype, device
@@ -56,7 +59,20 @@ class YOLOv9:
             a = np.ascontiguousarray(arr, dtype=np.float32)
             shp = (C.c_int64 * max(a.ndim, 1))(*a.shape)
             _lib.check(L.cc_yolo_load(self._h, name.encode(), _lib.ptr(a), shp, a.ndim))
+        if calibration_frames is not None:
+            if dtype != "f16c":
+                raise ValueError('calibration_frames are for dtype "f16c"')
+            f = np.ascontiguousarray(as_numpy(calibration_frames))
+            if f.ndim != 4 or f.shape[3] != 3 or f.dtype not in (np.uint8, np.float32):
+                raise ValueError(f"calibration_frames must be (B,H,W,3) uint8 or float32, got {f.shape} {f.dtype}")
+            _lib.check(L.cc_yolo_calibrate(self._h, _lib.ptr(f), f.shape[0], f.shape[1], f.shape[2], int(f.dtype == np.float32)))
         _lib.check(L.cc_yolo_finalize(self._h))
+
+    def calibration_info(self):
+        """dtype "f16c": (packed 1x1 convs rounded by the calibration-aware recursion, convs left to the plain controlled rounding)."""
+        a, b = C.c_int(), C.c_int()
+        _lib.check(_lib.lib().cc_yolo_calibration_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     # -- reference surface ------------------------------------------------------------------------
     def __call__(self, frame) -> Tensor:

@@ -29,6 +29,9 @@ extern "C" {
                          /* a 3x3 filter's taps; a 1x1 has nothing to balance).  Measured as close to f32 as CC_DTYPE_F16S on un-rounded      */
                          /* checkpoints at 1.15x instead of 2x the MFMA issue of CC_DTYPE_F16 (bench default)                              */
 
+#define CC_DTYPE_F16C 5  /* calibrated mode (detector only): one f16 plane per conv (two in the stem conv), the 1x1 convs' weights rounded with    */
+                         /* the errors steered by their inputs' second moments on calibration frames (cc_yolo_calibrate): CC_DTYPE_F16's rate     */
+
 #define CC_MAX_DET 300   /* rows per frame of the detector output (detection/yolov9.py:439) */
 
 const char* cc_last_error(void);
@@ -49,6 +52,17 @@ int cc_yolo_load(cc_yolo* h, const char* name, const float* data, const int64_t*
 /* Packs the loaded tensors into the device layout ([Cout][kh][kw][Cin], storage dtype). Fails if
  * any parameter of the graph is missing. */
 int cc_yolo_finalize(cc_yolo* h);
+/* dtype 5 ("f16c"): f16 activations and ONE f16 weight plane per conv (two in the stem conv), the 1x1 convs' float32 weights rounded to
+ * f16 by a calibration-aware recursion (GPTQ: rounding errors steered by the second moments of each conv's own input) that cc_yolo_finalize
+ * runs on an internal float32 pass over calibration frames: plain f16's frame rate, "f16h"'s tolerance on inputs like the calibration
+ * frames (INTEGRATION.md says what was measured with mismatched ones).  cc_yolo_calibrate hands over the frames ((B,H,W,3) BGR uint8 or
+ * float32 HOST memory, copied) between cc_yolo_load and cc_yolo_finalize; without it four frames of seeded white noise are used.
+ * cc_yolo_calibration_info: packed 1x1 convs the recursion rounded / left to the plain controlled rounding (singular second moments). */
+int cc_yolo_calibrate(cc_yolo* h, const void* frames, int B, int H, int W, int frame_f32);
+int cc_yolo_calibration_info(cc_yolo* h, int* n_calibrated, int* n_fallback);
+/* Host-only helper (no GPU needed; tests): the recursion itself - w (cout,cin) float32, H (cin,cin) float64 second moments of the input,
+ * damp (ridge on H as a share of its mean diagonal; 0.03 in the library) -> out (cout,cin) float32 values exactly representable in f16. */
+int cc_gptq_round_f16(const float* w, int64_t cout, int64_t cin, const double* H, double damp, float* out);
 /* YOLOv9.__call__ (yolov9.py:375-388) over a batch: frames (B,H,W,3) BGR, uint8 (frame_f32=0, the
  * production path clearcam.py:582) or float32 (frame_f32=1, the MOT path run_mot.py:33);
  * out (B,300,6) float32 [x1,y1,x2,y2,conf,cls] in source-frame pixels, suppressed rows zero.

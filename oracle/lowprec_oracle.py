@@ -132,5 +132,24 @@ class LowPrecOracle(YOLOv9Oracle):
         return self.q(super().network_input(frames))
 
 
+def gptq_f16(w: torch.Tensor, H: torch.Tensor, damp: float = 0.01) -> torch.Tensor:
+    """Checker for clearcam_amd/csrc/calibrate.hip ``gptq_round_f16`` (dtype "f16c"): w (co, ci) f32, H (ci, ci) f64 second moments of the
+    conv's input -> f16-representable f32 weights.  The GPTQ column walk (Frantar et al. 2022, restated from the paper): H + damp mean(diag) I
+    is inverted, U = chol(H^-1)^T upper triangular; column i is rounded to nearest f16 and its error, divided by U[i, i], is fed forward into
+    the columns behind it along U[i, i+1:].  torch.linalg factorisations in float64 (the library uses its own plain loops)."""
+    Wm = w.double().clone()
+    ci = Wm.shape[1]
+    Hd = H.clone().double()
+    Hd += torch.eye(ci, dtype=torch.float64) * damp * Hd.diag().mean()
+    U = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True)
+    Q = torch.empty_like(Wm)
+    for i in range(ci):
+        q = Wm[:, i].float().to(torch.float16).double()
+        Q[:, i] = q
+        if i + 1 < ci:
+            Wm[:, i + 1:] -= ((Wm[:, i] - q) / U[i, i])[:, None] * U[i, i + 1:][None, :]
+    return Q.float()
+
+
 def rel_rms(a: torch.Tensor, b: torch.Tensor) -> float:
     return float(torch.sqrt(((a - b) ** 2).mean() / (b ** 2).mean()))

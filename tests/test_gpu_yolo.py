@@ -377,9 +377,9 @@ def test_decode_topk_nms_exact_given_same_logits(sd_t, shift):
 #        4.6 px - and keeping DDetect's box branch in f32 changes nothing (the error arrives with P3..P5).  It stays a speed mode
 #        with its own, stated bars: >= 90 % strict matches, >= 95 % IoU matches, per-anchor median within 1e-3 * max(H, W),
 #        scores within 1e-2, P3/P4/P5 within 3e-2.
-BARS_16BIT = {"bf16": 3e-2, "f16": 4e-3, "f16s": 4e-3, "f16h": 4e-3}
-MATCH_16BIT = {"bf16": 0.90, "f16": 0.985, "f16s": 0.985, "f16h": 0.985}
-SCORE_16BIT = {"bf16": 1e-2, "f16": 2e-3, "f16s": 2e-3, "f16h": 2e-3}
+BARS_16BIT = {"bf16": 3e-2, "f16": 4e-3, "f16s": 4e-3, "f16h": 4e-3, "f16c": 4e-3}
+MATCH_16BIT = {"bf16": 0.90, "f16": 0.985, "f16s": 0.985, "f16h": 0.985, "f16c": 0.985}
+SCORE_16BIT = {"bf16": 1e-2, "f16": 2e-3, "f16s": 2e-3, "f16h": 2e-3, "f16c": 2e-3}
 
 
 _CASES = {}                                            # the last two f32-oracle runs: parametrised tests share their 64-frame case
@@ -463,6 +463,12 @@ def check_16bit_against_oracle(m, dtype, frames, ref, feats, dec_ref, min_dets):
         # deterministic: worst anchor 0.375 / 0.303 / 0.351 px in f16h, 0.629 / 0.124 / 0.187 px in f16s; profiles/r04w_final_modes_*.txt),
         # although the worst anchor of a set is a heavy-tailed draw of the f16 activation rounding ("The tail")
         assert s["anchor_box_err_px_max"] <= tol, (dtype, s)
+    elif dtype == "f16c":
+        # the calibrated mode, whatever the calibration frames were: the detection and score bars of the tolerance modes, 99 % of the anchors
+        # within the tolerance and at most 0.3 % beyond it.  The worst anchor of a frame set is a heavy-tailed draw in EVERY f16-activation
+        # mode (profiles/r05n_tail_256.txt: exact-weight f16s reads 19 px on one of 256 frames of this checkpoint), so it is not asserted here
+        assert yo.tolerance_bars(s)["detections"], (dtype, yo.tolerance_bars(s), s)
+        assert s["anchor_box_err_px_p99"] <= tol and s["anchors_over_tol"] <= 0.003 * s["anchors_both_over_thr"], (dtype, s)
     elif dtype == "f16":
         assert s["anchor_box_err_px_max"] <= tol, (dtype, s)                 # 16-bit-exact weights: the same anchor's box, every anchor both sides report
     else:
@@ -539,6 +545,60 @@ def test_tolerance_modes_on_other_checkpoints(seed):
         s = check_16bit_against_oracle(m, dtype, frames, ref, feats, dec_ref, min_dets=250)
         print(f"checkpoint seed {seed}, {dtype}: {s}")
         m.close()
+
+
+def calibration_frames(kind, n=4):
+    """Calibration inputs for dtype "f16c" that are NOT the test frames: white noise from another seed, or deliberately mismatched
+    distributions - heavily blurred noise with stretched contrast ("smooth"), 32x32 constant blocks ("blocks")."""
+    fr = np.random.default_rng(4242).integers(0, 256, (n, 640, 640, 3), dtype=np.uint8)
+    if kind == "smooth":
+        x = torch.from_numpy(fr).float().permute(0, 3, 1, 2)
+        for _ in range(3):
+            x = F.avg_pool2d(F.pad(x, (8, 8, 8, 8), mode="reflect"), 17, 1)
+        x = (x - x.mean((2, 3), keepdim=True)) / x.std((2, 3), keepdim=True) * 50 + 128
+        fr = x.clamp(0, 255).permute(0, 2, 3, 1).to(torch.uint8).numpy().copy()
+    elif kind == "blocks":
+        fr = np.ascontiguousarray(np.repeat(np.repeat(fr[:, ::32, ::32], 32, 1), 32, 2))
+    return fr
+
+
+@pytest.mark.parametrize("seed,calib", [(1234, None), (1234, "noise"), (1234, "smooth"), (1234, "blocks"), (7, None), (99, None)])
+def test_calibrated_mode_holds_the_tolerance_bars(seed, calib):
+    """dtype "f16c" (one f16 plane per conv, two in the stem; the 1x1 convs' weights rounded by the calibration-aware recursion at finalize)
+    on the conditioned checkpoints with their float32 weights un-rounded, against the f32 ORACLE on the frame sets of the split-weight tests:
+    >= 98.5 % strict matches clear of the threshold, scores within 2e-3, 99 % of the anchors within 0.64 px and at most 0.3 % beyond it
+    (matched calibration also holds "f16h"'s 99.9 % / 0.96 px bars on these sets with damping 0.01; the 256-frame record in
+    profiles/r05n_tail_256.txt is the better statistic).  calib None = the library's default (seeded noise generated inside cc_yolo_finalize); "noise" = other
+    white-noise frames handed over through cc_yolo_calibrate; "smooth" / "blocks" = calibration frames from ANOTHER distribution than the
+    test frames.  Plain f16 (the same single plane, controlled rounding) fails these bars on two of the three checkpoints."""
+    frames = noise_frames(1, 64, 640, 640) if seed == 1234 else noise_frames(seed, 32, 640, 640)
+    sd, ref, feats, dec_ref = conditioned_case(frames, exact=False, seed=seed)
+    from clearcam_amd.yolov9 import YOLOv9
+    m = YOLOv9("c", 640, state_dict=sd, dtype="f16c", calibration_frames=None if calib is None else calibration_frames(calib))
+    done, fallback = m.calibration_info()
+    assert done >= 50 and fallback == 0, (done, fallback)
+    s = check_16bit_against_oracle(m, "f16c", frames, ref, feats, dec_ref, min_dets=500 if seed == 1234 else 250)
+    print(f"f16c checkpoint {seed} calibration {calib}: {s}")
+    one = m.detect_batch(frames[:1])
+    assert np.array_equal(one[0], m.detect_batch(frames)[0])                  # deterministic and batch-invariant like every other mode
+    m.close()
+
+
+def test_calibrated_mode_is_reproducible_and_refuses_misuse(sd_t):
+    """Two handles calibrated on the same frames give identical rows (the recursion is deterministic: fixed sample positions, fixed thread-
+    independent arithmetic); cc_yolo_calibrate on a handle of another dtype, or after finalize, is an error."""
+    from clearcam_amd._lib import CCError
+    from clearcam_amd.yolov9 import YOLOv9
+    frames = noise_frames(2, 2, 320, 320)
+    cal = noise_frames(9, 2, 320, 320)
+    a = YOLOv9("t", 320, state_dict=sd_t, dtype="f16c", calibration_frames=cal)
+    b = YOLOv9("t", 320, state_dict=sd_t, dtype="f16c", calibration_frames=cal)
+    assert np.array_equal(a.detect_batch(frames), b.detect_batch(frames))
+    with pytest.raises(ValueError):
+        YOLOv9("t", 320, state_dict=sd_t, dtype="f16h", calibration_frames=cal)
+    L = _lib.lib()
+    assert L.cc_yolo_calibrate(a._h, _lib.ptr(cal), 2, 320, 320, 0) != 0      # after finalize
+    a.close(); b.close()
 
 
 def test_conditioned_checkpoint_f32_mode():
