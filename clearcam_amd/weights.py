@@ -13,7 +13,7 @@ weights come out in this container and on the GPU box.
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -193,6 +193,12 @@ def synthetic_yolov9_state_dict(size: str = "c", seed: int = 1234, scales=None) 
 # the measured perturbation gains and 16-bit emulation results are in assets/synth_cond_report.json.
 COND_EPS, COND_STD, COND_RES_FRAC, COND_BIAS_JITTER = 0.2, 0.1, 0.6, 0.02
 COND_DFL_STD, COND_DFL_RAMP, COND_CLS_BIAS, COND_Q, COND_ACTIVE_CLASSES = 0.5, 0.15, -1.8, 3e-4, 80
+# Stress variants of the conditioned checkpoint (round 5): the same construction with a larger share of white filter and larger
+# pre-activations - a network that amplifies perturbations, between the benign checkpoint (f32 perturbation gain 1.4-2 from the input to
+# P3..P5) and the chaotic seeded one (30-60x).  name -> (COND_EPS, COND_STD); measured gains in assets/synth_cond_report.json:
+# "g3" 2.8 / 3.5 / 3.9 at P3 / P4 / P5, "g10" 8.1 / 11 / 13.
+COND_STRESS = {"g3": (1.0, 0.3), "g10": (1.0, 0.6)}
+COND_STRESS_CLS_SHIFT = {"g3": 0.4, "g10": 0.0}         # class-logit bias shift: g3's logits are narrow, without it 0-1 detections per frame
 _BINOMIAL3 = (np.outer([1.0, 2.0, 1.0], [1.0, 2.0, 1.0]) / 16.0).astype(np.float32)
 _COND = {}
 
@@ -212,16 +218,18 @@ def _storage_exact(w: np.ndarray) -> np.ndarray:
     return r
 
 
-def conditioned_base_weights(size: str, seed: int = 1234) -> Dict[str, np.ndarray]:
-    """The seeded filters BEFORE calibration: unit gain, zero bias except the seeded jitter (see the block comment)."""
+def conditioned_base_weights(size: str, seed: int = 1234, eps: Optional[float] = None) -> Dict[str, np.ndarray]:
+    """The seeded filters BEFORE calibration: unit gain, zero bias except the seeded jitter (see the block comment).
+    eps: share of white filter in the 3x3 kernels (default COND_EPS; the stress variants use more)."""
     rng = np.random.Generator(np.random.PCG64(seed))
+    eps = COND_EPS if eps is None else eps
     sd: Dict[str, np.ndarray] = {}
     for prefix, cin, cout, k, g, bare in yolo_specs(size):
         cg = cin // g
         if k == 3:
             mix = rng.standard_normal((cout, cg, 1, 1), dtype=np.float32)
             white = rng.standard_normal((cout, cg, 3, 3), dtype=np.float32)
-            w = (mix * _BINOMIAL3[None, None] * np.float32(16.0 / 6.0) + np.float32(COND_EPS) * white) / np.float32(math.sqrt(1.0 + COND_EPS ** 2))
+            w = (mix * _BINOMIAL3[None, None] * np.float32(16.0 / 6.0) + np.float32(eps) * white) / np.float32(math.sqrt(1.0 + eps ** 2))
         else:
             w = rng.standard_normal((cout, cg, k, k), dtype=np.float32)
         w -= w.mean(axis=(1, 2, 3), keepdims=True, dtype=np.float64).astype(np.float32)
@@ -259,7 +267,7 @@ def unpack_cond_table(size: str, gain: np.ndarray, bias: np.ndarray, jitter: np.
     return table
 
 
-def conditioned_yolov9_state_dict(size: str = "c", seed: int = 1234, table=None, exact: bool = True) -> Dict[str, np.ndarray]:
+def conditioned_yolov9_state_dict(size: str = "c", seed: int = 1234, table=None, exact: bool = True, stress: Optional[str] = None) -> Dict[str, np.ndarray]:
     """Seeded, well-conditioned YOLOv9 state dict (same keys and shapes as the reference's checkpoints).
 
     weight = base filter x gain[conv] (x per-class gain in the head), rounded to values bf16 and f16 hold exactly;
@@ -269,18 +277,23 @@ def conditioned_yolov9_state_dict(size: str = "c", seed: int = 1234, table=None,
     exact=False keeps the float32 products un-rounded, so that a 16-bit mode's re-quantisation of the WEIGHTS is part of
     what a comparison with the f32 oracle measures (as with a trained f32 checkpoint).  On this network that term is
     the larger one by construction: its 3x3 filters are low-pass, which attenuates white activation-rounding noise at
-    every layer but passes the smooth, signal-correlated error of a perturbed filter (per-block table in DESIGN.md section 5)."""
+    every layer but passes the smooth, signal-correlated error of a perturbed filter (per-block table in DESIGN.md section 5).
+
+    stress="g3" / "g10" (COND_STRESS, seed 1234 only): the construction with more white filter and larger pre-activations, a network
+    whose f32 perturbation gain is ~3-5 / ~8-14 instead of ~1.5 - how far the 16-bit modes' tolerance claim reaches."""
+    if stress is not None and (stress not in COND_STRESS or seed != 1234):
+        raise ValueError(f"stress must be one of {sorted(COND_STRESS)} (seed 1234)")
     if table is None:
-        tag = size if seed == 1234 else f"{size}_s{seed}"          # the table is data-dependent: one per (size, seed) of base filters
+        tag = f"{size}_{stress}" if stress else (size if seed == 1234 else f"{size}_s{seed}")   # the table is data-dependent: one per set of base filters
         if tag not in _COND:
             import os
             path = os.path.join(os.path.dirname(__file__), "assets", f"synth_cond_{tag}.npz")
             if not os.path.exists(path):
-                raise FileNotFoundError(f"no conditioned checkpoint table for size '{size}' seed {seed} ({path}); run tools/calibrate_synth.py cond {size} --seed {seed}")
+                raise FileNotFoundError(f"no conditioned checkpoint table for size '{size}' seed {seed} stress {stress} ({path}); run tools/calibrate_synth.py cond {size} --seed {seed} / --stress NAME")
             with np.load(path) as z:
                 _COND[tag] = unpack_cond_table(size, z["gain"], z["bias"], z["jitter"])
         table = _COND[tag]
-    sd = conditioned_base_weights(size, seed)
+    sd = conditioned_base_weights(size, seed, COND_STRESS[stress][0] if stress else None)
     for key in list(sd):
         if not key.endswith(".weight") or sd[key].ndim != 4 or ".dfl." in key:
             continue
@@ -290,6 +303,8 @@ def conditioned_yolov9_state_dict(size: str = "c", seed: int = 1234, table=None,
         jitter = np.float32(table.get("j:" + prefix, 0.0))
         shift = np.asarray(table.get("b:" + prefix, 0.0), np.float32)
         sd[prefix + ".bias"] = (sd[prefix + ".bias"] * jitter + shift).astype(np.float32)
+    if stress and COND_STRESS_CLS_SHIFT.get(stress):
+        sd = shift_class_bias(sd, COND_STRESS_CLS_SHIFT[stress])
     return sd
 
 

@@ -601,6 +601,41 @@ def test_calibrated_mode_is_reproducible_and_refuses_misuse(sd_t):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("stress", ["g3", "g10"])
+def test_tolerance_modes_on_stress_checkpoints(stress):
+    """How far the tolerance claim reaches: the conditioned construction with a measured f32 perturbation gain of ~3-4 ("g3") and ~8-14 ("g10")
+    from the network input to P3..P5 (clearcam_amd/assets/synth_cond_report.json; the benign checkpoints read 1.4-1.9, the chaotic one 30-60),
+    float32 weights un-rounded, against the f32 CPU oracle.  g3: every f16-activation mode keeps the median anchor within 0.05 px, 97 % of the
+    detections strictly matched and all but at most one frame of the set free of anchors beyond the tolerance (profiles/r05p_stress_128.txt:
+    one frame of 128 carries every such anchor, in every mode).  g10: no 16-bit mode holds the tolerance - exact-weight f16s included, so it
+    is f16 ACTIVATION rounding amplified by the network - and the test only guards against gross breakage (finite rows, f16s at least as
+    close as plain f16).  INTEGRATION.md states this limit next to the modes' claims."""
+    from clearcam_amd.weights import conditioned_yolov9_state_dict
+    frames = noise_frames(31, 16, 640, 640)
+    sd = conditioned_yolov9_state_dict("c", 1234, exact=False, stress=stress)
+    o = yo.YOLOv9Oracle("c", 640, sd)
+    det, dec = [], []
+    with torch.no_grad():
+        for i in range(0, len(frames), 4):
+            y = o.decode(o.head_raw(o.features(o.network_input(frames[i:i + 4]))))
+            dec.append(yo.decoded_rows(y)); det.append(o.scale_boxes((640, 640), o.postprocess(y), (640, 640)).numpy())
+    ref, dec_ref = np.concatenate(det), np.concatenate(dec)
+    med = {}
+    for dtype in ("f16h", "f16s", "f16c", "f16"):
+        m = _yolo("c", 640, sd, dtype)
+        got = m.detect_batch(frames); d = m.get_tensor("decoded"); m.close()
+        assert np.isfinite(got).all()
+        s = yo.parity_summary(ref, got, 0.64, dec_ref, d)
+        both = (dec_ref[..., 4] > 0) & (d[..., 4] > 0)
+        bad_frames = int(((np.where(both, np.abs(dec_ref[..., :4] - d[..., :4]).max(-1), 0.0) > 0.64).sum(1) > 0).sum())
+        print(f"stress {stress} {dtype}: frames with anchors beyond 0.64 px {bad_frames}/16", {k: round(float(s[k]), 4) for k in ("match_frac", "anchor_box_err_px_p50", "anchor_box_err_px_p99", "anchor_box_err_px_max")})
+        med[dtype] = s["anchor_box_err_px_p50"]
+        assert s["anchors_both_over_thr"] >= 500, s
+        if stress == "g3" and dtype != "f16":
+            assert s["anchor_box_err_px_p50"] <= 0.05 and s["match_frac"] >= 0.97 and bad_frames <= 1, (dtype, bad_frames, s)
+    assert med["f16s"] <= 1.1 * med["f16"] + 1e-3, med
+
+
 def test_conditioned_checkpoint_f32_mode():
     """The conditioned checkpoint through the f32 parity mode: the tight f32 bars hold on it too (restored in round 5: the 16-bit
     tolerance modes are judged against the oracle, and this pins the library's own f32 mode to the same oracle on the same network)."""

@@ -67,9 +67,11 @@ def calibrate(size: str, seed: int = 1234, res: int = 640):
 
 # ---- the well-conditioned checkpoint ---------------------------------------------------------------------------------
 
-def calibrate_conditioned(size: str, seed: int = 1234, res: int = 640, n_frames: int = 8):
-    """-> table {"g:<conv>": gain (scalar, or per output channel in the head), "b:<conv>": bias shift per channel, "j:<conv>": jitter}."""
-    o = YOLOv9Oracle(size, res, W.conditioned_base_weights(size, seed))      # unit gains, the seeded N(0,1) bias draws
+def calibrate_conditioned(size: str, seed: int = 1234, res: int = 640, n_frames: int = 8, eps=None, std=None):
+    """-> table {"g:<conv>": gain (scalar, or per output channel in the head), "b:<conv>": bias shift per channel, "j:<conv>": jitter}.
+    eps / std: the stress variants' share of white filter and pre-activation std (clearcam_amd.weights.COND_STRESS)."""
+    o = YOLOv9Oracle(size, res, W.conditioned_base_weights(size, seed, eps))      # unit gains, the seeded N(0,1) bias draws
+    std = W.COND_STD if std is None else std
     base_bias = {k: v.clone() for k, v in o.sd.items() if k.endswith(".bias")}
     table = {}
     orig = o._conv2d
@@ -93,7 +95,7 @@ def calibrate_conditioned(size: str, seed: int = 1234, res: int = 640, n_frames:
                 gain, jitter = W.COND_DFL_STD / s, 0.0
                 shift = -(m * gain) + W.COND_DFL_RAMP * (torch.arange(len(s)) % 16 - 7.5)
         else:
-            target = W.COND_STD * (W.COND_RES_FRAC if (".m.list." in name and name.endswith("cv2.conv")) else 1.0)
+            target = std * (W.COND_RES_FRAC if (".m.list." in name and name.endswith("cv2.conv")) else 1.0)
             gain = torch.full_like(s, target / float(s.mean()))
             jitter = W.COND_BIAS_JITTER * target
             shift = -(m * gain)
@@ -167,15 +169,21 @@ if __name__ == "__main__":
         seed = 1234
         if "--seed" in argv:                                        # further checkpoints: assets/synth_cond_<size>_s<seed>.npz
             seed = int(argv[argv.index("--seed") + 1]); del argv[argv.index("--seed"):argv.index("--seed") + 2]
+        stress = None
+        if "--stress" in argv:                                      # stress variants: assets/synth_cond_<size>_<name>.npz (weights.COND_STRESS)
+            stress = argv[argv.index("--stress") + 1]; del argv[argv.index("--stress"):argv.index("--stress") + 2]
         sizes = argv or ["c"]
         rpath = os.path.join(ASSETS, "synth_cond_report.json")
         report = json.load(open(rpath)) if os.path.exists(rpath) else {}
         for size in sizes:
-            tag = size if seed == 1234 else f"{size}_s{seed}"
-            table = calibrate_conditioned(size, seed)
+            tag = f"{size}_{stress}" if stress else (size if seed == 1234 else f"{size}_s{seed}")
+            eps, std = W.COND_STRESS[stress] if stress else (None, None)
+            table = calibrate_conditioned(size, seed, eps=eps, std=std)
             np.savez_compressed(os.path.join(ASSETS, f"synth_cond_{tag}.npz"), **W.pack_cond_table(size, table))
             W._COND.pop(tag, None)
-            report[tag] = conditioning_report(size, W.conditioned_yolov9_state_dict(size, seed))
+            report[tag] = conditioning_report(size, W.conditioned_yolov9_state_dict(size, seed, stress=stress))
+            if stress:
+                report[tag]["stress"] = {"eps": eps, "preact_std": std}
             report[tag]["design"] = {"eps": W.COND_EPS, "preact_std": W.COND_STD, "dfl_std": W.COND_DFL_STD, "dfl_ramp": W.COND_DFL_RAMP, "cls_bias": W.COND_CLS_BIAS, "quantile": W.COND_Q, "active_classes": W.COND_ACTIVE_CLASSES}
             print(tag, json.dumps(report[tag], indent=1), flush=True)
         json.dump(report, open(rpath, "w"), indent=1, sort_keys=True)

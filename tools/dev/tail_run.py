@@ -10,7 +10,7 @@ from clearcam_amd.yolov9 import YOLOv9
 from oracle.yolov9_oracle import parity_summary, tolerance_bars
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 modes = (sys.argv[2] if len(sys.argv) > 2 else "f16,f16h,f16s,f16c,f16c:smooth,f16c:blocks").split(",")
-seeds = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1234,7,99").split(",")]
+seeds = [x if x.startswith("g") else int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1234,7,99").split(",")]   # g3 / g10: the stress variants
 def cal(kind, n=4):
     fr = np.random.default_rng(4242).integers(0, 256, (n, 640, 640, 3), dtype=np.uint8)
     if kind == "smooth":
@@ -29,8 +29,8 @@ def run(m, fr):
 keys = ("match_frac", "match_frac_clear_of_threshold", "anchor_box_err_px_p50", "anchor_box_err_px_p99", "anchor_box_err_px_p999", "anchor_box_err_px_max", "anchors_over_tol", "anchors_both_over_thr", "frames_with_anchors_over_tol", "worst_frame_share", "anchor_score_err_max")
 print(f"# {nf} white-noise frames per checkpoint, reference = this library's f32 mode, box tolerance 0.64 px; damp {os.environ.get('CLEARCAM_CALIB_DAMP', 'default')}")
 for seed in seeds:
-    sd = conditioned_yolov9_state_dict("c", seed, exact=False)
-    fr = np.random.default_rng(1000 + seed).integers(0, 256, (nf, 640, 640, 3), dtype=np.uint8)
+    sd = conditioned_yolov9_state_dict("c", 1234, exact=False, stress=seed) if isinstance(seed, str) else conditioned_yolov9_state_dict("c", seed, exact=False)
+    fr = np.random.default_rng(1000 + (1234 if isinstance(seed, str) else seed)).integers(0, 256, (nf, 640, 640, 3), dtype=np.uint8)
     m = YOLOv9("c", 640, state_dict=sd, dtype="f32"); ref, dec_ref = run(m, fr); m.close()
     for mode in modes:
         dt, _, kind = mode.partition(":")
