@@ -119,10 +119,10 @@ void cc_yolo_destroy(cc_yolo* h);
 int cc_conv2d_nhwc(int dtype, const void* x_dev, int B, int H, int W, int Cin, const float* w_oihw,
                    const float* bias, int Cout, int k, int stride, int groups, int act, void* out_dev,
                    int force_direct, void* stream);
-/* Diagnostic (kernel tuning, tools/dev/phase_ab.py): average device milliseconds of one launch of the conv above on random
+/* Diagnostic (kernel tuning, tools/dev/stream_ab.py, variant_sweep.py): average device milliseconds of one launch of the conv above on random
  * 16-bit data resident in HBM, weights packed once, `iters` launches between two events.  Not part of the drop-in surface. */
 int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int stride, int act, int variant, int iters, float* ms);
-/* Diagnostic (kernel tuning, tools/dev/attn_ab.py): average device milliseconds of one attention launch (B images, L tokens, H heads of 64)
+/* Diagnostic (kernel tuning): average device milliseconds of one attention launch (B images, L tokens, H heads of 64)
  * on random 16-bit data; abl: 0 the kernel, 1 K / V staging only, 2 tiles without staging.  Not part of the drop-in surface. */
 int cc_attn_bench(int dtype, int B, int L, int H, int causal, int abl, int iters, float* ms);
 /* Host-only helper (no GPU needed; tests / tooling): the CONTROLLED rounding cc_yolo_finalize applies to a conv's OIHW float32 weights
