@@ -43,7 +43,10 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 //   slot of tile u is free after global barrier 2u + 2: group 0 refills it (tile u + S) after Q_{u+1}, group 1 after Q_u.
 // ABL (development, timing only - results are WRONG with any bit set): 1 no MFMA, 2 no fragment reads, 4 no activation arithmetic,
 // 8 no DMA inside the loop, 16 no stores.
-template <class T, int WN, int KT, int CINC, int NP, int ABL = 0>
+// LATE: the activation arithmetic runs behind barrier Q, in the memory phase (beside the OTHER group's MFMAs), instead of right after the
+// wave's own MFMAs: per tile 2 x max(MFMA, VALU + memory issue) instead of 2 x (MFMA + VALU) - pays where the MFMA phase is the longer one
+// (two weight planes).
+template <class T, int WN, int KT, int CINC, int NP, int ABL = 0, int LATE = 0>
 __global__ __launch_bounds__(512) void conv_stream_kernel(const ConvP p, const StreamAux a) {
   constexpr int NT = 2, WM = 8 / WN;
   constexpr int PT = WM * NP * 16;                     // pixels per tile
@@ -213,9 +216,12 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const ConvP p, const S
         ov[pt] = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
       }
     };
-    if (p.act == 1) finish(std::integral_constant<int, 1>{});
-    else if (p.act == 2) finish(std::integral_constant<int, 2>{});
-    else finish(std::integral_constant<int, 0>{});
+    auto finish_rt = [&]() {
+      if (p.act == 1) finish(std::integral_constant<int, 1>{});
+      else if (p.act == 2) finish(std::integral_constant<int, 2>{});
+      else finish(std::integral_constant<int, 0>{});
+    };
+    if constexpr (!LATE) finish_rt();
     if (grp == 1 && t + 1 < nmine) {                   // tile t + 1's pieces: due before global barrier 2 (t + 1), this group's Q_t
       const int left = nmine - 2 - t;
       wait_tile(left < S - 2 ? left : S - 2, t < S - 2 ? t : S - 2);
@@ -226,6 +232,7 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const ConvP p, const S
     // been freed.  Stores FIRST: the vector-memory queue is in order, and behind a freshly issued tile of loads a store waits (and parks its
     // wave, and with it the barrier) until the loads ahead of it have been sent off.
     if (a.flags & 2) __builtin_amdgcn_s_setprio(2);
+    if constexpr (LATE) finish_rt();
     const int mb = (bx + t * G) * PT + wm * NP * 16 + r;
 #pragma unroll
     for (int pt = 0; pt < NP; ++pt) {
@@ -269,20 +276,20 @@ bool conv_stream_legal(const ConvP& p) { StreamCfg c; return stream_cfg(p, c); }
 
 int g_stream_flags = 2;                                // cc_dev_set("stream_flags", bits): StreamAux::flags
 int g_stream_abl = 0;                                  // cc_dev_set("stream_abl", bits): timing ablations of the f16 256 -> 256 shapes (development)
-template <class T, int WN, int KT, int CINC, int NP, int ABL = 0> static void launch_stream_k(const ConvP& p, hipStream_t stream) {
+template <class T, int WN, int KT, int CINC, int NP, int ABL = 0, int LATE = 0> static void launch_stream_k(const ConvP& p, hipStream_t stream) {
   constexpr int PT = (8 / WN) * NP * 16;
   constexpr size_t lds = (size_t)4 * PT * (CINC / 2) * 128;
   static PerDevice pd;
   const int d = pd.index();
   if (pd.first(d))
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stream_kernel<T, WN, KT, CINC, NP, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stream_kernel<T, WN, KT, CINC, NP, ABL, LATE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int cus = pd.cu_count(d);
   StreamAux a{};
   a.M = p.B * p.Ho * p.Wo;
   a.ntiles = (a.M + PT - 1) / PT;
   a.flags = g_stream_flags;
-  note_launch("conv_stream", conv_stream_kernel<T, WN, KT, CINC, NP, ABL>, (long)a.ntiles, 512, lds, std::min(a.ntiles, cus));
-  hipLaunchKernelGGL((conv_stream_kernel<T, WN, KT, CINC, NP, ABL>), dim3(std::min(a.ntiles, cus)), dim3(512), lds, stream, p, a);
+  note_launch("conv_stream", conv_stream_kernel<T, WN, KT, CINC, NP, ABL, LATE>, (long)a.ntiles, 512, lds, std::min(a.ntiles, cus));
+  hipLaunchKernelGGL((conv_stream_kernel<T, WN, KT, CINC, NP, ABL, LATE>), dim3(std::min(a.ntiles, cus)), dim3(512), lds, stream, p, a);
 }
 
 template <class T> static void launch_stream_t(const ConvP& p, const StreamCfg& c, hipStream_t stream) {
@@ -294,10 +301,23 @@ template <class T> static void launch_stream_t(const ConvP& p, const StreamCfg& 
 #undef CC_ABL_CASE
     }
   }
-  if (p.Cout == 256 && p.Cin == 256) { if (pl == 2) launch_stream_k<T, 8, 16, 8, 4>(p, stream); else launch_stream_k<T, 8, 8, 8, 4>(p, stream); }
-  else if (p.Cout == 256 && p.Cin == 512) launch_stream_k<T, 8, 16, 16, 2>(p, stream);
-  else if (p.Cout == 128) { if (pl == 2) launch_stream_k<T, 4, 8, 4, 4>(p, stream); else launch_stream_k<T, 4, 4, 4, 4>(p, stream); }
-  else { if (pl == 2) launch_stream_k<T, 2, 4, 2, 4>(p, stream); else launch_stream_k<T, 2, 2, 2, 4>(p, stream); }
+  // flags bit 4: the activation arithmetic in the memory phase (LATE) - A/B per shape (cc_dev_set("stream_flags"))
+  static const bool env_once = [] { if (const char* e = getenv("CLEARCAM_STREAM_FLAGS")) g_stream_flags = atoi(e); return true; }();
+  (void)env_once;
+  const bool late = (g_stream_flags & 4) != 0;
+  if (p.Cout == 256 && p.Cin == 256) {
+    if (pl == 2) { if (late) launch_stream_k<T, 8, 16, 8, 4, 0, 1>(p, stream); else launch_stream_k<T, 8, 16, 8, 4>(p, stream); }
+    else { if (late) launch_stream_k<T, 8, 8, 8, 4, 0, 1>(p, stream); else launch_stream_k<T, 8, 8, 8, 4>(p, stream); }
+  }
+  else if (p.Cout == 256 && p.Cin == 512) { if (late) launch_stream_k<T, 8, 16, 16, 2, 0, 1>(p, stream); else launch_stream_k<T, 8, 16, 16, 2>(p, stream); }
+  else if (p.Cout == 128) {
+    if (pl == 2) { if (late) launch_stream_k<T, 4, 8, 4, 4, 0, 1>(p, stream); else launch_stream_k<T, 4, 8, 4, 4>(p, stream); }
+    else { if (late) launch_stream_k<T, 4, 4, 4, 4, 0, 1>(p, stream); else launch_stream_k<T, 4, 4, 4, 4>(p, stream); }
+  }
+  else {
+    if (pl == 2) { if (late) launch_stream_k<T, 2, 4, 2, 4, 0, 1>(p, stream); else launch_stream_k<T, 2, 4, 2, 4>(p, stream); }
+    else { if (late) launch_stream_k<T, 2, 2, 2, 4, 0, 1>(p, stream); else launch_stream_k<T, 2, 2, 2, 4>(p, stream); }
+  }
   (void)c;
 }
 
