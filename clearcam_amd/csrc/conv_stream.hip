@@ -6,7 +6,8 @@
 //   * ALL weights of the layer live in REGISTERS for the life of the block: wave (wn, wm) holds the rows of its 32 output channels for
 //     every K chunk (2 x KT x 16 bytes per lane: 128 registers at K = 512), loaded once from L2;
 //   * pixel rows stream HBM -> LDS through a four-slot ring of 32 KB tiles by LDS-DMA (global_load_lds_dwordx4), three tiles ahead of the
-//     one being multiplied; the queue is never drained: counted vmcnt over the DMA pieces AND the output stores (both retire in issue order);
+//     one being multiplied; the loads are never drained: counted vmcnt over the DMA pieces of later tiles (by default the stores issued since are
+//     assumed acknowledged - they are half a tile old - so nothing rests on stores and loads retiring in one order; StreamAux::flags bit 8);
 //   * ONE barrier per tile; no weight traffic, no loader tables, no per-tile set-up beyond four address computations per lane;
 //   * two weight planes (ConvP::split, dtype f16s / f16h): the K walk visits the tile's channels twice against the second half of the weight
 //     row - the same LDS image, no second HBM read;
@@ -18,7 +19,7 @@
 
 namespace cc {
 
-struct StreamAux { int ntiles, M, flags; };   // flags (cc_dev_set("stream_flags")): 1 = raised priority for the MFMA phase, 2 = for the memory phase
+struct StreamAux { int ntiles, M, flags; };   // flags (cc_dev_set("stream_flags") / CLEARCAM_STREAM_FLAGS, default 10): 1 = raised priority for the MFMA phase, 2 = for the memory phase, 4 = activation arithmetic in the memory phase (LATE), 8 = waits count loads only
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // a register quadruple an asm operand can name (HIP's uint4 is a struct)
 
 // runtime-valued counted wait: N = pieces and stores issued after the DMA pieces that must have landed (multiples of 2 up to 24)
@@ -143,7 +144,12 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const ConvP p, const S
 
   // ops this wave issued after the pieces of the tile it now needs: d later tiles' pieces, the stores of st tiles (both retire in issue order).
   // Per iteration a wave issues stores(t) and then the pieces of ONE later tile (group 0: t - 1 + S, group 1: t + S), after the S tiles of the prologue.
-  auto wait_tile = [&](int d, int st) { wait_vmcnt_dyn(d * NPIECE + st * Q); };
+  // flags bit 8 (DEFAULT ON): the wait does not rest on stores retiring in issue order with the loads - it waits as if every store issued
+  // since had already been acknowledged, so only later tiles' pieces may stay outstanding (loads do return in order).  Counting the stores
+  // as well (bit 8 off: allowed on gfx9-class counters, where LLVM itself treats loads and stores as one in-order event class) measured the
+  // same: 12.17 vs 12.18 ms per step on the same box - the stores of half a tile ago have long been acknowledged.
+  const bool loads_only = (a.flags & 8) != 0;
+  auto wait_tile = [&](int d, int st) { wait_vmcnt_dyn(d * NPIECE + (loads_only ? 0 : st * Q)); };
   auto barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -274,7 +280,7 @@ static bool stream_cfg(const ConvP& p, StreamCfg& c) {
 }
 bool conv_stream_legal(const ConvP& p) { StreamCfg c; return stream_cfg(p, c); }
 
-int g_stream_flags = 2;                                // cc_dev_set("stream_flags", bits): StreamAux::flags
+int g_stream_flags = 10;                               // cc_dev_set("stream_flags", bits): StreamAux::flags
 int g_stream_abl = 0;                                  // cc_dev_set("stream_abl", bits): timing ablations of the f16 256 -> 256 shapes (development)
 template <class T, int WN, int KT, int CINC, int NP, int ABL = 0, int LATE = 0> static void launch_stream_k(const ConvP& p, hipStream_t stream) {
   constexpr int PT = (8 / WN) * NP * 16;
