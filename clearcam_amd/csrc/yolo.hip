@@ -1098,19 +1098,25 @@ void pool_stream_put(int device, hipStream_t s) {
 
 void grow_slot_streams(int device, hipStream_t base, std::vector<hipStream_t>& slots, int n_extra) {
   std::vector<hipStream_t> rejected;
-  bool fresh = false;                                    // after the first rejection the pool is bypassed: what it holds next may be exactly the
-  while ((int)slots.size() < n_extra) {                  // streams an earlier call rejected for this base (they share its hardware queue)
+  // Rejected streams are held out of the pool until the end, so a call never draws the same stream twice: it works through what the pool
+  // holds (possibly the very streams an earlier call rejected for this base - they share its hardware queue) and then through fresh
+  // ones.  The attempt budget therefore covers the pooled streams PLUS twelve fresh ones; the pool only grows when everything it held
+  // was rejected (an unconditional "fresh after the first rejection" grew it by a stream per depth change: tools/dev/soak.py flight).
+  size_t pooled = 0;
+  { std::lock_guard<std::mutex> lk(g_pool_mu); pooled = g_pool[device].size(); }
+  while ((int)slots.size() < n_extra) {
     hipStream_t t = nullptr;
-    for (int attempt = 0; attempt < 12; ++attempt) {
-      t = pool_stream_get(device, fresh);
+    const int budget = (int)pooled + 12;
+    for (int attempt = 0; attempt < budget; ++attempt) {
+      t = pool_stream_get(device);
       bool ok = streams_overlap(base, t);
       for (size_t j = 0; ok && j < slots.size(); ++j) ok = streams_overlap(slots[j], t);
       if (ok) break;
-      if (attempt == 11) {
-        fprintf(stderr, "[clearcam] warning: no stream found that overlaps with the handle's other slots after 12 attempts: batches in flight on this slot will serialise\n");
+      if (attempt == budget - 1) {
+        fprintf(stderr, "[clearcam] warning: no stream found that overlaps with the handle's other slots after %d attempts: batches in flight on this slot will serialise\n", budget);
         break;
       }
-      rejected.push_back(t); t = nullptr; fresh = true;   // held until the end, so that the runtime moves on to another queue
+      rejected.push_back(t); t = nullptr;               // held until the end, so that the pool / the runtime moves on to another queue
     }
     slots.push_back(t);
   }

@@ -42,8 +42,10 @@ def flight_round(n):
     clip.set_in_flight(1)
     torch.cuda.synchronize()
 _orig_round = one_round
+part = sys.argv[1] if len(sys.argv) > 1 else "all"                  # all | entry (every entry point) | flight (depth changes, submissions)
 def one_round(n):
-    _orig_round(n); flight_round(n)
+    if part in ("all", "entry"): _orig_round(n)
+    if part in ("all", "flight"): flight_round(n)
 one_round(5); base = free(); t0 = time.time()
 for r in range(6):
     one_round(40); print(f"round {r}: free {free():.0f} MB (drift {base - free():+.1f} MB), index rows {len(ix)}", flush=True)
