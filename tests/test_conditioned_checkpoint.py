@@ -97,3 +97,20 @@ def test_storage_rounding_alone_meets_the_gpu_bars(sd, dtype, feat_bar):
             tot += (a, c, k); sc = max(sc, se)
     assert tot[0] >= 100 and tot[2] >= 0.95 * max(tot[0], tot[1]), tot
     assert sc <= 1e-2, sc
+
+
+@pytest.mark.parametrize("stress,lo,hi", [("g3", 2.0, 6.0), ("g10", 6.0, 20.0)])
+def test_stress_checkpoints_are_pinned_and_amplify_as_stated(stress, lo, hi):
+    """The stress variants (weights.COND_STRESS: more white filter, larger pre-activations): pinned by digest, the reference's key set, and the
+    committed report's measured f32 perturbation gain from the network input to P3 / P4 / P5 inside the stated band - between the benign
+    checkpoints (<= 2) and the chaotic one (30-60).  tests/test_gpu_yolo.py::test_tolerance_modes_on_stress_checkpoints states what the
+    16-bit modes do there."""
+    d = W.conditioned_yolov9_state_dict("c", 1234, stress=stress)
+    assert _digest(d) == open(os.path.join(os.path.dirname(__file__), "golden", f"synth_cond_c_{stress}.sha256")).read().strip()
+    assert set(d) == set(W.conditioned_yolov9_state_dict("c", 1234))
+    rep = json.load(open(os.path.join(os.path.dirname(W.__file__), "assets", "synth_cond_report.json")))[f"c_{stress}"]
+    g = rep["f32_perturbation_gain_at_p3_p4_p5"]["network input"]
+    assert lo <= min(g) and max(g) <= hi, g
+    assert rep["stress"] == {"eps": W.COND_STRESS[stress][0], "preact_std": W.COND_STRESS[stress][1]}
+    with pytest.raises(ValueError):
+        W.conditioned_yolov9_state_dict("c", 7, stress=stress)               # the stress tables exist for seed 1234 only
