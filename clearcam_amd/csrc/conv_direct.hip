@@ -119,6 +119,39 @@ __global__ __launch_bounds__(256) void pool_vec_kernel(const PoolP p) {
   *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
 }
 
+// ADown's avg_pool2d(2, stride 1, pad 0) (detection/yolov9.py:45) with R output rows per thread (round 5): the R + 1 input rows of a
+// thread's two columns are loaded once - 2 (R + 1) loads for R outputs instead of 4 R, all in flight together - and every output sums its
+// four taps in the order of pool_vec_kernel<T, 2, 0> ((r0,s0) + (r0,s1) + (r1,s0) + (r1,s1), then x 0.25): the same bits.
+template <class T, int R>
+__global__ __launch_bounds__(256) void avg2_rows_kernel(const PoolP p) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int CV = p.C / E;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= p.Wo * CV) return;
+  const int wo = x / CV, cv = x - wo * CV, ho0 = blockIdx.y * R, b = blockIdx.z;
+  const T* in = reinterpret_cast<const T*>(p.in) + p.in_coff + cv * E;
+  uint4 u[R + 1][2];
+#pragma unroll
+  for (int r = 0; r <= R; ++r) {
+    const int ih = min(ho0 + r, p.H - 1);                  // rows past the map are loaded (clamped) and never used
+#pragma unroll
+    for (int c = 0; c < 2; ++c) u[r][c] = *reinterpret_cast<const uint4*>(in + ((size_t)(b * p.H + ih) * p.W + (wo + c)) * p.in_cstride);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int ho = ho0 + r;
+    if (ho >= p.Ho) break;
+    float a0[E], a1[E], b0[E], b1[E];
+    unpack_chunk<T>(u[r][0], a0); unpack_chunk<T>(u[r][1], a1); unpack_chunk<T>(u[r + 1][0], b0); unpack_chunk<T>(u[r + 1][1], b1);
+    uint4 o;
+    T* t = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < E; ++e) t[e] = from_f32<T>((((0.f + a0[e]) + a1[e]) + b0[e] + b1[e]) * 0.25f);
+    const size_t m = ((size_t)b * p.Ho + ho) * p.Wo + wo;
+    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
+  }
+}
+
 // ADown's second branch (detection/yolov9.py:47-51): avg_pool2d(2, stride 1) followed by max_pool2d(3, stride 2, pad 1)
 // on the same channels, in one pass: out(ho,wo) = max over the 3x3 window of pooled positions (2ho-1+r, 2wo-1+s) inside
 // [0,H-2]x[0,W-2] of the 2x2 average there.  The full-resolution averaged tensor is never written or read back.
@@ -172,6 +205,60 @@ __global__ __launch_bounds__(256) void avgmax_pool_kernel(const PoolP p) {
   *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
 }
 
+// avgmax_pool_kernel with two output rows per thread (round 5): the 4x4 windows of vertically adjacent outputs share two input rows, so
+// six rows x four columns are loaded once (24 loads for two outputs instead of 32).  Same window walk and summation order per output.
+template <class T>
+__global__ __launch_bounds__(256) void avgmax_rows2_kernel(const PoolP p) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int CV = p.C / E;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= p.Wo * CV) return;
+  const int wo = x / CV, cv = x - wo * CV, ho0 = blockIdx.y * 2, b = blockIdx.z;
+  const T* in = reinterpret_cast<const T*>(p.in) + p.in_coff + cv * E;
+  const int i0 = 2 * ho0 - 1, j0 = 2 * wo - 1;             // top-left input pixel of the first output's window
+  uint4 u[6][4];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int ic = min(max(i0 + r, 0), p.H - 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int jc = min(max(j0 + c, 0), p.W - 1);
+      u[r][c] = *reinterpret_cast<const uint4*>(in + ((size_t)(b * p.H + ic) * p.W + jc) * p.in_cstride);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int ho = ho0 + q;
+    if (ho >= p.Ho) break;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ph = i0 + 2 * q + r;
+      float top[4][E], bot[4][E];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { unpack_chunk<T>(u[2 * q + r][c], top[c]); unpack_chunk<T>(u[2 * q + r + 1][c], bot[c]); }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int pw = j0 + s;
+        const bool ok = ph >= 0 && ph <= p.H - 2 && pw >= 0 && pw <= p.W - 2;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float a = (((top[s][e] + top[s + 1][e]) + bot[s][e]) + bot[s + 1][e]) * 0.25f;
+          acc[e] = fmaxf(acc[e], ok ? a : -INFINITY);
+        }
+      }
+    }
+    uint4 o;
+    T* t = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < E; ++e) t[e] = from_f32<T>(acc[e]);
+    const size_t m = ((size_t)b * p.Ho + ho) * p.Wo + wo;
+    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + m * p.out_cstride + p.out_coff + cv * E) = o;
+  }
+}
+
 // Scalar fallback: one thread per (pixel, channel), any channel count / alignment.
 template <class T>
 __global__ __launch_bounds__(256) void pool_kernel(const PoolP p) {
@@ -205,8 +292,19 @@ template <class T> static void launch_pool_t(const PoolP& p, hipStream_t stream)
   const dim3 vgrid((unsigned)((p.Wo * (p.C / E) + 255) / 256), (unsigned)p.Ho, (unsigned)p.B);
   if (p.mode == 2) {
     CC_CHECK(vec && p.k == 3 && p.stride == 2 && p.pad == 1, "avg-max pool: needs 16-byte channel chunks, k=3 s=2 p=1");
-    hipLaunchKernelGGL(avgmax_pool_kernel<T>, vgrid, dim3(256), 0, stream, p);
+    static const int rows2 = [] { const char* e = getenv("CLEARCAM_POOL_ROWS"); return e ? atoi(e) : 4; }();
+    if (rows2 != 1 && p.Ho >= 32) hipLaunchKernelGGL(avgmax_rows2_kernel<T>, dim3(vgrid.x, (unsigned)((p.Ho + 1) / 2), vgrid.z), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(avgmax_pool_kernel<T>, vgrid, dim3(256), 0, stream, p);
   } else if (vec && p.mode == 0 && p.k == 2) {
+    // stride 1, no padding, at least 64 rows: eight output rows per thread (CLEARCAM_POOL_ROWS=4 / 1: four / one).  Pools per 64-frame step:
+    // 0.726 ms with one row, 0.660 with four (+ two rows in the avg-max kernel), 0.654 with eight - same bits (profiles/r05t_pool_rows.txt)
+    static const int rows = [] { const char* e = getenv("CLEARCAM_POOL_ROWS"); return e ? atoi(e) : 8; }();
+    const bool plain = p.stride == 1 && p.pad == 0 && p.Ho >= 64 && p.Wo == p.W - 1 && p.Ho == p.H - 1;
+    if (rows == 8 && plain)
+      hipLaunchKernelGGL((avg2_rows_kernel<T, 8>), dim3(vgrid.x, (unsigned)((p.Ho + 7) / 8), vgrid.z), dim3(256), 0, stream, p);
+    else if (rows == 4 && plain)
+      hipLaunchKernelGGL((avg2_rows_kernel<T, 4>), dim3(vgrid.x, (unsigned)((p.Ho + 3) / 4), vgrid.z), dim3(256), 0, stream, p);
+    else
     hipLaunchKernelGGL((pool_vec_kernel<T, 2, 0>), vgrid, dim3(256), 0, stream, p);
   } else if (vec && p.mode == 1 && p.k == 1) {                       // AdaFace's MaxPool2d(1, stride) shortcut: a strided copy
     hipLaunchKernelGGL((pool_vec_kernel<T, 1, 1>), vgrid, dim3(256), 0, stream, p);
