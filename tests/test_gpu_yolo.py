@@ -987,6 +987,24 @@ def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fu
     assert np.abs(a["p3"]).max() > 0.05 and np.isfinite(a["p3"]).all()
 
 
+def test_pool_rows_per_thread_same_bits(tmp_path):
+    """ADown's pools with eight / four output rows per thread (2x2 average; the avg-max kernel takes two) against one row per thread
+    (CLEARCAM_POOL_ROWS, read once per process): every output sums its taps in the same order, so features and detections are IDENTICAL -
+    on maps whose height is not a multiple of the rows per thread (270 x 480 frames: 152 x 160 letterboxed maps at stride 4 -> 79, 39, 19 rows)."""
+    import subprocess
+    import sys
+    outs = []
+    for rows in ("1", "4", "8"):
+        path = str(tmp_path / f"pool{rows}.npz")
+        env = dict(os.environ, CLEARCAM_POOL_ROWS=rows, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", _CSP_SCRIPT, "c", "640", "f16", "270", "480", "3", path], check=True, env=env)
+        outs.append(np.load(path))
+    for other in outs[1:]:
+        for n in ("p3", "p4", "p5", "det"):
+            assert np.array_equal(outs[0][n], other[n]), n
+    assert (outs[0]["det"][..., 4] > 0).sum() > 10
+
+
 @pytest.mark.parametrize("dtype", ["f16", "f16s"])
 def test_head_entry_split_equals_single_launch(tmp_path, dtype):
     """DDetect's two entry convs per level (box 64 + class 256 channels over the same map) as two launches - the class conv on the
