@@ -300,6 +300,7 @@ template <class T, int WN, int KT, int CINC, int NP, int ABL = 0, int LATE = 0> 
 
 template <class T> static void launch_stream_t(const ConvP& p, const StreamCfg& c, hipStream_t stream) {
   const int pl = p.split ? 2 : 1;
+#ifdef CC_STREAM_ABLATIONS                              // development build only (HIPCC_EXTRA=-DCC_STREAM_ABLATIONS python clearcam_amd/build.py --force; tools/dev/stream_ablate.py)
   if constexpr (std::is_same<T, f16_t>::value) {
     if (g_stream_abl && p.Cout == 256 && p.Cin == 256) {
 #define CC_ABL_CASE(b) case b: if (pl == 2) launch_stream_k<T, 8, 16, 8, 4, b>(p, stream); else launch_stream_k<T, 8, 8, 8, 4, b>(p, stream); return;
@@ -307,6 +308,9 @@ template <class T> static void launch_stream_t(const ConvP& p, const StreamCfg& 
 #undef CC_ABL_CASE
     }
   }
+#else
+  CC_CHECK(!g_stream_abl, "timing ablations of the streaming kernel need a development build (-DCC_STREAM_ABLATIONS)");
+#endif
   // flags bit 4: the activation arithmetic in the memory phase (LATE) - A/B per shape (cc_dev_set("stream_flags"))
   static const bool env_once = [] { if (const char* e = getenv("CLEARCAM_STREAM_FLAGS")) g_stream_flags = atoi(e); return true; }();
   (void)env_once;

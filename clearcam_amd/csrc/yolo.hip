@@ -1234,15 +1234,17 @@ static void calibrate_1x1(cc_yolo* h) {
   auto work = [&]() {
     for (size_t i; (i = next.fetch_add(1)) < items.size();) {
       Item& it = items[i];
-      std::vector<double> Hm;
-      second_moments(it.X.data(), it.rows, it.ci, Hm);
-      std::vector<float>().swap(it.X);
-      for (auto& n : it.names) {
-        HostTensor& w = h->host[n + ".weight"];
-        std::vector<float> q(w.data.size());
-        const int rc = gptq_round_f16(w.data.data(), (int)w.shape[0], it.ci, Hm.data(), damp, q.data());
-        if (rc == 0) w.data.swap(q); else it.rc = rc;
-      }
+      try {
+        std::vector<double> Hm;
+        second_moments(it.X.data(), it.rows, it.ci, Hm);
+        std::vector<float>().swap(it.X);
+        for (auto& n : it.names) {
+          HostTensor& w = h->host.at(n + ".weight");                  // every key exists (checked above); at() does not modify the map: safe from several threads
+          std::vector<float> q(w.data.size());
+          const int rc = gptq_round_f16(w.data.data(), (int)w.shape[0], it.ci, Hm.data(), damp, q.data());
+          if (rc == 0) w.data.swap(q); else it.rc = rc;
+        }
+      } catch (...) { it.rc = -3; }                                  // out of memory on a worker: the conv keeps controlled rounding
     }
   };
   const unsigned nt = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), (unsigned)items.size()}));

@@ -1,5 +1,6 @@
 # dev tool (GPU): timing ablations of conv_stream_kernel on 256 -> 256 at 160x160, B = 64 (cc_dev_set("stream_abl", bits); results are wrong
 # with any bit set): 1 no MFMA, 2 no fragment reads, 4 no activation arithmetic, 8 no DMA inside the loop, 16 no stores.
+# Needs a development build of the library: HIPCC_EXTRA=-DCC_STREAM_ABLATIONS python clearcam_amd/build.py --force
 import ctypes as C, sys
 from clearcam_amd import _lib
 L = _lib.lib()
