@@ -8,7 +8,8 @@
 //   * pixel rows stream HBM -> LDS through a four-slot ring of 32 KB tiles by LDS-DMA (global_load_lds_dwordx4), three tiles ahead of the
 //     one being multiplied; the loads are never drained: counted vmcnt over the DMA pieces of later tiles (by default the stores issued since are
 //     assumed acknowledged - they are half a tile old - so nothing rests on stores and loads retiring in one order; StreamAux::flags bit 8);
-//   * ONE barrier per tile; no weight traffic, no loader tables, no per-tile set-up beyond four address computations per lane;
+//   * two barriers per tile (two wave groups half a tile apart, below); no weight traffic, no loader tables, no per-tile set-up beyond
+//     four pointer increments per lane;
 //   * two weight planes (ConvP::split, dtype f16s / f16h): the K walk visits the tile's channels twice against the second half of the weight
 //     row - the same LDS image, no second HBM read;
 //   * the epilogue stores from registers: the (MFMA row -> output channel) permutation below gives every lane 8 consecutive channels of one
@@ -35,18 +36,18 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // WN waves along the output channels (32 each: Cout = 32 WN), 8 / WN along the pixels; KT = K chunks of 32 (Ktot / 32, both planes);
 // CINC = input-channel chunks of 32 (Cin / 32; KT = CINC or 2 CINC); NP = 16-pixel MFMA tiles per wave and ring slot.
 //
-// Two wave groups half a tile period apart (waves w and w + 4 share a SIMD): every wave passes two barriers per tile, P before its MFMA
-// phase and Q before its epilogue phase (next DMA pieces, bias + SiLU, stores), and group 1 passes one extra barrier before the loop - so
-// global barrier 2t .. 2t+1 has group 0 multiplying tile t beside group 1 finishing tile t - 1, and 2t+1 .. 2t+2 the reverse: on every
-// SIMD the matrix pipe of one wave runs beside the VALU / memory issue of the other (measured with both in lockstep: time = memory +
-// compute, 3.9 TB/s at 256 -> 256; profiles/r05a_stream_ab.txt).
+// Two wave groups half a tile period apart (waves w and w + 4 share a SIMD): every wave passes two barriers per tile, P before its compute
+// phase (MFMAs, then bias + SiLU + pack in registers) and Q before its memory phase (this tile's stores, the next tile's DMA pieces), and
+// group 1 passes one extra barrier before the loop - so global barrier 2t .. 2t+1 has group 0 computing tile t beside group 1 storing
+// tile t - 1, and 2t+1 .. 2t+2 the reverse: on every SIMD one wave computes while the other sits in vector-memory issue (both in
+// lockstep measured 3.9 TB/s at 256 -> 256, this 4.1; docs/rounds/r05.md has the ablations and what did not help).
 //   pieces of tile u land before global barrier 2u: group 0 waits for its own before P_u, group 1 before Q_{u-1};
 //   slot of tile u is free after global barrier 2u + 2: group 0 refills it (tile u + S) after Q_{u+1}, group 1 after Q_u.
 // ABL (development, timing only - results are WRONG with any bit set): 1 no MFMA, 2 no fragment reads, 4 no activation arithmetic,
 // 8 no DMA inside the loop, 16 no stores.
-// LATE: the activation arithmetic runs behind barrier Q, in the memory phase (beside the OTHER group's MFMAs), instead of right after the
-// wave's own MFMAs: per tile 2 x max(MFMA, VALU + memory issue) instead of 2 x (MFMA + VALU) - pays where the MFMA phase is the longer one
-// (two weight planes).
+// LATE (A/B only, flags bit 4): the activation arithmetic behind barrier Q, in the memory phase beside the OTHER group's MFMAs.  On paper
+// 2 x max(MFMA, VALU + memory issue) per tile instead of 2 x (MFMA + VALU); measured 10-15 % slower in the plan (profiles/r05r_*): a wave
+// parked at store issue holds its arithmetic up with it.
 template <class T, int WN, int KT, int CINC, int NP, int ABL = 0, int LATE = 0>
 __global__ __launch_bounds__(512) void conv_stream_kernel(const ConvP p, const StreamAux a) {
   constexpr int NT = 2, WM = 8 / WN;
