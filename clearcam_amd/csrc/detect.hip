@@ -191,9 +191,14 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemP p) {
               return (r - sr0) * dpr * 4 + (int)sh;                      // the row's first byte, modulo its aligned dword
             };
             const int r0 = rowoff(y0), r1 = rowoff(y1), c0 = (x0 - sc0) * 3, c1 = (x1 - sc0) * 3;
+            if ((wx | wy) == 0) {                                        // both weights zero (frames already at the network's size: the letterbox is
+#pragma unroll                                                           // the identity): lerp_u8(a, b, 0) IS a - one byte per channel instead of four
+              for (int c = 0; c < 3; ++c) v[c] = scratch[r0 + c0 + c];
+            } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
               v[c] = lerp_u8(lerp_u8(scratch[r0 + c0 + c], scratch[r0 + c1 + c], wx), lerp_u8(scratch[r1 + c0 + c], scratch[r1 + c1 + c], wx), wy);
+            }
           } else {
             const uint8_t* f = reinterpret_cast<const uint8_t*>(q.frames);
             const size_t a00 = ((img + y0) * q.W + x0) * 3, a01 = ((img + y0) * q.W + x1) * 3, a10 = ((img + y1) * q.W + x0) * 3, a11 = ((img + y1) * q.W + x1) * 3;
