@@ -150,3 +150,37 @@ def test_calibration_aware_rounding_host(lib_path):
         assert abs(proxy(out) / proxy(ref) - 1) < 0.02 and proxy(out) < 0.5 * proxy(near), (proxy(out), proxy(ref), proxy(near))
     bad = -np.eye(8)                                                               # not positive definite even with the damping: reported, not rounded
     assert L.cc_gptq_round_f16(_lib.ptr(np.zeros((4, 8), np.float32)), 4, 8, _lib.ptr(bad), 0.01, _lib.ptr(np.zeros((4, 8), np.float32))) != 0
+
+
+def test_calibration_aware_rounding_generalises_to_held_out_pixels(lib_path):
+    """The point of dtype "f16c", checked on the CPU: second moments of a REAL 1x1 conv input (the f32 oracle's activations entering block 4's
+    cv1 of the conditioned YOLOv9-C checkpoint, one noise frame) taken on half of the pixels; the weights cc_gptq_round_f16 returns for that
+    conv have a smaller output error E|dW x|^2 than round-to-nearest on the OTHER half of the pixels (and on the pixels of another frame) -
+    by the factor the recursion promises on its own calibration set, within a small margin."""
+    import torch
+    from clearcam_amd.weights import conditioned_yolov9_state_dict
+    from oracle import yolov9_oracle as yo
+    sd = conditioned_yolov9_state_dict("c", 1234, exact=False)
+    name = "model.list.4.cv1.conv"
+    o = yo.YOLOv9Oracle("c", 320, sd)
+    seen = {}
+    orig = o._conv2d
+    def hooked(x, n, stride=1, groups=1):
+        if n == name:
+            seen.setdefault("x", []).append(x.clone())
+        return orig(x, n, stride, groups)
+    o._conv2d = hooked
+    frames = np.random.default_rng(8).integers(0, 256, (2, 320, 320, 3), dtype=np.uint8)
+    with torch.no_grad():
+        o.features(o.network_input(frames[:1])); o.features(o.network_input(frames[1:]))
+    X = [x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).double().numpy() for x in seen["x"]]
+    cal, held, other = X[0][0::2], X[0][1::2], X[1]
+    w = np.ascontiguousarray(sd[name + ".weight"][:, :, 0, 0])
+    H = np.ascontiguousarray(cal.T @ cal / len(cal))
+    q = np.empty_like(w)
+    _lib.check(_lib.lib().cc_gptq_round_f16(_lib.ptr(w), w.shape[0], w.shape[1], _lib.ptr(H), 0.03, _lib.ptr(q)))
+    near = w.astype(np.float16).astype(np.float32)
+    err = lambda qq, xs: float((((qq - w).astype(np.float64) @ xs.T) ** 2).mean())      # noqa: E731  E|dW x|^2 over pixels and output channels
+    gains = {k: err(near, xs) / err(q, xs) for k, xs in (("calibration", cal), ("held-out pixels", held), ("another frame", other))}
+    print(gains)
+    assert gains["calibration"] > 3.0 and gains["held-out pixels"] > 0.8 * gains["calibration"] and gains["another frame"] > 0.6 * gains["calibration"], gains
