@@ -463,6 +463,91 @@ def traced_kernel_ms(default_cfg: bool, dtype: str, device_name: str):
     return rec if ok else None
 
 
+MAX_LINE_BYTES = 4096                                           # the driver keeps an 8 KB tail of stdout: the final line must fit with room to spare
+
+
+def compact_line(d: dict) -> dict:
+    """The ONE stdout line (contract fields + roofline + cpu_baseline + a parity verdict, < 4 KB).  Everything else this run
+    measured stays in the detail record (bench_detail.json + stderr): VERDICT r5 item 1 - the r05 line had grown to 25 KB and the
+    driver's 8 KB tail could not parse it."""
+    def pick(src, keys):
+        return {k: src[k] for k in keys if isinstance(src, dict) and k in src and src[k] is not None}
+    out = pick(d, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    out["vs_baseline"] = d.get("vs_baseline")
+    out.update(pick(d, ("dtype", "storage_mode", "data")))
+    cfg = d.get("config") or {}
+    out["config"] = pick(cfg, ("workload", "batch_per_gpu", "batches_in_flight", "parallelism"))
+    r = d.get("roofline") or {}
+    roof = pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_rocprofv3", "kernel_ms_per_step", "kernel_ms_per_step_rocprofv3",
+                    "traffic", "launches_per_step", "frac_mfma_issued"))
+    roof["kernel"] = "every conv launch of the step (implicit-GEMM MFMA kernels), one batch in flight"
+    if isinstance(r.get("per_launch_roof"), dict):
+        roof["per_launch_roof_frac"] = r["per_launch_roof"].get("frac")
+        tq = r["per_launch_roof"].get("tile_quantisation")
+        if isinstance(tq, dict):
+            roof["idle_slot_ms"] = tq.get("idle_slot_ms")
+    roof.setdefault("traffic", None)
+    roof["traffic_unit"] = "HBM bytes per step, rocprofv3 PMC (profiles/pmc_traffic.json), conv launches"
+    out["roofline"] = roof
+    c = d.get("cpu_baseline")
+    if isinstance(c, dict):
+        cb = pick(c, ("value", "unit", "cores", "kind", "host_cores"))
+        cb["sample"] = str(c.get("sample", ""))[:160]
+        out["cpu_baseline"] = cb
+    p = d.get("parity")
+    if isinstance(p, dict):
+        if "error" in p:
+            out["parity"] = {"error": str(p["error"])[:200]}
+        else:
+            out["parity"] = {"holds": p.get("holds_tolerance_with_unrounded_weights"),
+                             "worst_anchor_px": p.get("worst_anchor_box_err_px_with_unrounded_weights"),
+                             "every_anchor": p.get("every_anchor_within_tolerance_with_unrounded_weights"),
+                             "f32_gate": pick(p.get("f32_chaotic_checkpoint") or {}, ("match_frac", "box_err_px_max_strict", "score_err_max", "anchor_box_err_px_max"))}
+    one = d.get("one_batch_in_flight")
+    if isinstance(one, dict):
+        out["one_batch_in_flight_frames_per_sec"] = one.get("frames_per_sec")
+    if isinstance(d.get("frames_per_sec_by_storage_dtype"), dict):
+        out["frames_per_sec_by_storage_dtype"] = d["frames_per_sec_by_storage_dtype"]
+    if isinstance(d.get("single_frame"), dict):
+        out["single_frame_ms_p50"] = d["single_frame"].get("ms_p50")
+    cl = d.get("clip")
+    if isinstance(cl, dict):
+        out["clip"] = pick(cl, ("image_embeds_per_sec", "image_batch", "image_frac_of_mfma_peak", "seconds_per_10k_crops"))
+    st = d.get("streams")
+    if isinstance(st, dict):
+        out["streams"] = {k: (pick(v, ("frames_per_sec", "fps_per_camera")) if isinstance(v, dict) else v) for k, v in st.items() if not isinstance(v, str)}
+    out.update(pick(d, ("ranks_seen", "ms_per_step_by_rank", "storage_mode_by_rank", "streams_multi_gpu")))
+    sh = d.get("search_sharded")
+    if isinstance(sh, dict):
+        out["search_sharded"] = {k: v for k, v in sh.items() if not isinstance(v, (str, dict, list)) or k == "error"}
+    out["detail"] = "bench_detail.json"
+    return out
+
+
+def emit(detail: dict) -> None:
+    """Write the full record to bench_detail.json (repo root, and gpurun_out/ when it exists) and to stderr; print the compact line
+    as the LAST line of stdout.  Optional blocks are dropped, least important first, should the line ever exceed MAX_LINE_BYTES."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    blob = json.dumps(detail, indent=1)
+    for path in (os.path.join(root, "bench_detail.json"), os.path.join(root, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(blob)
+        except OSError as exc:                   # a read-only tree must not cost the line
+            print(f"bench: could not write {path}: {exc}", file=sys.stderr)
+    print("bench detail: " + json.dumps(detail), file=sys.stderr, flush=True)
+    line = compact_line(detail)
+    for drop in ("streams", "search_sharded", "streams_multi_gpu", "clip", "frames_per_sec_by_storage_dtype", "parity"):
+        if len(json.dumps(line)) < MAX_LINE_BYTES:
+            break
+        line.pop(drop, None)
+    text = json.dumps(line)
+    assert len(text) < MAX_LINE_BYTES, len(text)
+    sys.stdout.flush()
+    print(text, flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -853,7 +938,7 @@ def main() -> None:
             line["search_sharded"] = sharded
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.size, args.res, with_clip=not args.no_clip)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
     if dist.is_initialized():

@@ -20,7 +20,13 @@ def run_bench(world, port, extra_env=None):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-3000:]                      # ONE JSON line, from rank 0 only
-    return json.loads(lines[0])
+    # the driver parses the LAST line of an 8 KB stdout tail (BENCH_r05.json.parsed was null: the r05 line was 25 KB)
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0]
+    assert len(lines[0]) < 4096, len(lines[0])
+    line = json.loads(lines[0])
+    detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))       # the full record lives beside bench.py
+    assert detail["value"] == line["value"] and "kernel_timing_note" in detail["roofline"]
+    return line
 
 
 def test_two_ranks_produce_one_weak_scaling_line():
@@ -40,6 +46,16 @@ def test_two_ranks_produce_one_weak_scaling_line():
     assert line["ranks_seen"] == 2
     pr = line["ms_per_step_by_rank"]
     assert len(pr) == 2 and all(v > 0 for v in pr) and pr[1] >= 2.0 and pr[1] <= line["ms_per_step"] * 1.5 + 1.0
+
+
+def test_single_rank_line_is_short_and_carries_roofline_and_cpu_baseline():
+    line = run_bench(1, 29645, {"CLEARCAM_CPU_SWEEP": "8"})
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["value"] > 0
+    for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "dtype", "storage_mode", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"]) and line["cpu_baseline"]["kind"] == "port"
+    assert "workload" in line["config"] and "model" not in line["config"]
 
 
 def test_a_failing_side_metric_on_one_rank_does_not_hang_or_kill_the_line():
