@@ -419,6 +419,10 @@ __global__ __launch_bounds__(512, 2) void csp_fused_kernel(const CspP p) {
   }
 }
 
+// csp_tile.hip (round 6): hidden width 32 with every weight resident in LDS in fragment order and 16 x 32-pixel tiles
+bool csp_tile_supported(int dt, int hid, int split);
+void launch_csp_tile(int dt, const CspP& p, hipStream_t stream);
+
 bool csp_fused_supported(int dt, int hid, int split) { return (dt == F16 || (dt == BF16 && !split)) && (hid == 32 || hid == 64); }
 
 template <class T, int HID, bool RES, int SPLIT = 0> static void launch_csp(const CspP& p, hipStream_t stream) {
@@ -443,6 +447,9 @@ void launch_csp_fused(int dt, const CspP& p0, hipStream_t stream) {
   const int s1 = p0.split != 0, s3 = p0.split == 1;
   CC_CHECK(p0.kw12 % 64 == 0 && p0.kw3 % 64 == 0 && p0.kwr % 64 == 0 && p0.kwb % 64 == 0 && p0.kwr >= 9 * p0.hid * (1 + s3) && p0.kwb >= 9 * p0.hid * (1 + s3) &&
            p0.kw12 >= 2 * p0.hid * (1 + s1) && p0.kw3 >= 2 * p0.hid * (1 + s1), "fused RepNCSP: weight rows must cover whole K slabs");
+  // CLEARCAM_CSP_TILE=0 keeps the round-2 kernel at hidden width 32 (A/B, tools/dev); read once per process
+  static const bool tile_on = [] { const char* e = getenv("CLEARCAM_CSP_TILE"); return e ? atoi(e) != 0 : true; }();
+  if (tile_on && !p0.stream && !p0.dbg && csp_tile_supported(dt, p0.hid, p0.split)) { launch_csp_tile(dt, p0, stream); return; }
   CspP p = p0;
   p.tx = (p.W + 15) / 16; p.tiles = ((p.H + 7) / 8) * p.tx;
   p.inv_tiles = 1.0f / (float)p.tiles; p.inv_tx = 1.0f / (float)p.tx;
