@@ -447,9 +447,14 @@ void launch_csp_fused(int dt, const CspP& p0, hipStream_t stream) {
   const int s1 = p0.split != 0, s3 = p0.split == 1;
   CC_CHECK(p0.kw12 % 64 == 0 && p0.kw3 % 64 == 0 && p0.kwr % 64 == 0 && p0.kwb % 64 == 0 && p0.kwr >= 9 * p0.hid * (1 + s3) && p0.kwb >= 9 * p0.hid * (1 + s3) &&
            p0.kw12 >= 2 * p0.hid * (1 + s1) && p0.kw3 >= 2 * p0.hid * (1 + s1), "fused RepNCSP: weight rows must cover whole K slabs");
-  // CLEARCAM_CSP_TILE=0 keeps the round-2 kernel at hidden width 32 (A/B, tools/dev); read once per process
-  static const bool tile_on = [] { const char* e = getenv("CLEARCAM_CSP_TILE"); return e ? atoi(e) != 0 : true; }();
-  if (tile_on && !p0.stream && !p0.dbg && csp_tile_supported(dt, p0.hid, p0.split)) { launch_csp_tile(dt, p0, stream); return; }
+  // CLEARCAM_CSP_TILE=0 keeps the round-2 kernel at hidden width 32 (A/B, tools/dev), =2 takes the round-6 kernel at every batch size
+  // (tests: small batches, ragged tiles); read once per process
+  static const int tile_mode = [] { const char* e = getenv("CLEARCAM_CSP_TILE"); return e ? atoi(e) : 1; }();
+  const bool tile_on = tile_mode != 0;
+  // ... from two rounds of its 16 x 32 tiles on: below that (a single frame: 50 tiles) this file's 128-pixel tiles spread over more CUs.
+  // Both are bit-identical to the four launches they replace, so the choice may depend on the batch size.
+  const long tiles32 = (long)p0.B * ((p0.H + 15) / 16) * ((p0.W + 31) / 32);
+  if (tile_on && !p0.stream && !p0.dbg && (tiles32 >= 512 || tile_mode == 2) && csp_tile_supported(dt, p0.hid, p0.split)) { launch_csp_tile(dt, p0, stream); return; }
   CspP p = p0;
   p.tx = (p.W + 15) / 16; p.tiles = ((p.H + 7) / 8) * p.tx;
   p.inv_tiles = 1.0f / (float)p.tiles; p.inv_tx = 1.0f / (float)p.tx;

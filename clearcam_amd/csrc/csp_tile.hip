@@ -22,6 +22,10 @@
 //  * Three barriers per tile (a complete / t complete / tile done), 2400 MFMAs between them.
 // The intermediates use 64-byte pixel rows with the 16-byte chunk index XORed by ((pixel >> 2) & 1) << 1: conflict-free for a
 // ds_read_b128 of sixteen consecutive pixels at ANY starting pixel (the taps of a 3x3 shift the window by single pixels).
+// Hidden width 64 (208 / 272 KB of weights: they must stream) was built the same way with 16 x 16 tiles and a two-slot 32 KB ring fed
+// through registers, one barrier per 24-32 KB chunk: bit-identical and SLOWER than csp_fused.hip's streaming variant (0.30 / 0.40 ms
+// against 0.22 / 0.26; 0.19 / 0.25 even with the weight stream switched off: nine barriers per 256-pixel tile, waves parked 44-63 %,
+// profiles/r06e_*) - removed; csp_fused.hip keeps hidden width 64.
 // K order of every accumulation (tap, plane, 32-channel step) and the rounding points are those of the four launches it replaces:
 // bit-identical (tests/test_gpu_yolo.py::test_fused_csp_equals_unfused).
 #include <utility>
@@ -317,7 +321,7 @@ void launch_csp_tile(int dt, const CspP& p0, hipStream_t stream) {
   CC_CHECK(p0.x_cstride % 8 == 0 && p0.x_coff % 8 == 0 && p0.out_cstride % 8 == 0 && p0.out_coff % 8 == 0 && (((uintptr_t)p0.x | (uintptr_t)p0.out) & 15) == 0,
            "tiled RepNCSP: views must be 16-byte aligned");
   const int s1 = p0.split != 0;
-  CC_CHECK(p0.kw12 >= 64 * (1 + s1) && p0.kw3 >= 64 * (1 + s1) && p0.kwr >= 288 && p0.kwb >= 288, "tiled RepNCSP: weight rows too short");
+  CC_CHECK(p0.kw12 >= 2 * p0.hid * (1 + s1) && p0.kw3 >= 2 * p0.hid * (1 + s1) && p0.kwr >= 9 * p0.hid && p0.kwb >= 9 * p0.hid, "tiled RepNCSP: weight rows too short");
   CspP p = p0;
   using G = CspTileGeom<0>;
   p.tx = (p.W + G::TW - 1) / G::TW; p.tiles = ((p.H + G::TH - 1) / G::TH) * p.tx;
