@@ -838,12 +838,14 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
     //  narrow 3x3 layers on a few tiles go to the weights-stationary kernel instead: 6.5-7.3 us against 8.5-10.5 at batch 1 (same K order))
     {   // thin 1x1 layers whose roof is HBM: all weights resident in registers, pixels streamed through an LDS ring (conv_stream.hip).
         // CLEARCAM_STREAM=0 disables; CLEARCAM_STREAM_MIN_PIX = fewest output pixels it is taken for; tests force it with variant 10.
-      static int stream_on = -1, stream_min = 0;
-      if (stream_on < 0) {
-        const char* e = getenv("CLEARCAM_STREAM"); stream_on = e ? atoi(e) : 1;
-        const char* m = getenv("CLEARCAM_STREAM_MIN_PIX"); stream_min = m ? atoi(m) : 200000;   // measured (B = 64, profiles/r05f_stream_ab.txt): 1.13-1.5x at 160x160 and 80x80, a tie at 40x40 (102 400 pixels), 0.75x at 20x20
-      }
-      const int on = g_stream_override >= 0 ? g_stream_override : stream_on;
+      // both values come from ONE thread-safe static (two plain statics let a second thread see stream_on set and stream_min still 0)
+      struct StreamEnv { int on, min_pix; };
+      static const StreamEnv env = [] {
+        const char* e = getenv("CLEARCAM_STREAM"); const char* m = getenv("CLEARCAM_STREAM_MIN_PIX");
+        return StreamEnv{e ? atoi(e) : 1, m ? atoi(m) : 200000};   // measured (B = 64, profiles/r05f_stream_ab.txt): 1.13-1.5x at 160x160 and 80x80, a tie at 40x40 (102 400 pixels), 0.75x at 20x20
+      }();
+      const int stream_min = env.min_pix;
+      const int on = g_stream_override >= 0 ? g_stream_override : env.on;
       if (p.variant == 10 || (p.variant == 0 && on && M >= stream_min && conv_stream_legal(p))) {
         launch_conv_stream(TypeTag<T>::dt, p, stream);
         return;

@@ -329,10 +329,14 @@ template <class T> static void launch_phase(const ConvP& p, const ConvAux& a, in
   const bool buf_ok = xb < ((size_t)1 << 32) - 256 && wbytes < ((size_t)1 << 32) - 256;
   b.x_bytes = (unsigned)xb; b.w_bytes = (unsigned)wbytes;
   if ((flags & 512) && conv_persist_ok(p)) { launch_conv_persist(TypeTag<T>::dt, (flags & 1024) ? 1 : 0, (flags >> 12) & 15, p, b, M, stream); return; }
-  note_launch("conv_phase", conv_phase_kernel<T, 1>, (long)((M + 255) / 256) * a.nt, 512, lds);
-  if ((flags & 64) && buf_ok && !a.two) { hipLaunchKernelGGL((conv_phase_kernel<T, 2>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b); return; }
-  if (flags & 32) hipLaunchKernelGGL((conv_phase_kernel<T, 1>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
-  else hipLaunchKernelGGL((conv_phase_kernel<T, 0>), dim3(((M + 255) / 256) * a.nt), dim3(512), lds, stream, p, b);
+  const long tiles = (long)((M + 255) / 256) * a.nt;                   // the note names the variant that is actually launched
+  if ((flags & 64) && buf_ok && !a.two) {
+    note_launch("conv_phase", conv_phase_kernel<T, 2>, tiles, 512, lds);
+    hipLaunchKernelGGL((conv_phase_kernel<T, 2>), dim3(tiles), dim3(512), lds, stream, p, b);
+    return;
+  }
+  if (flags & 32) { note_launch("conv_phase", conv_phase_kernel<T, 1>, tiles, 512, lds); hipLaunchKernelGGL((conv_phase_kernel<T, 1>), dim3(tiles), dim3(512), lds, stream, p, b); }
+  else { note_launch("conv_phase", conv_phase_kernel<T, 0>, tiles, 512, lds); hipLaunchKernelGGL((conv_phase_kernel<T, 0>), dim3(tiles), dim3(512), lds, stream, p, b); }
 }
 
 void launch_conv_phase(int dt, const ConvP& p, const ConvAux& a, int M, hipStream_t stream) {

@@ -267,6 +267,8 @@ static bool stream_cfg(const ConvP& p, StreamCfg& c) {
   if (p.Cin % 64 || p.s0.C != p.Cin || p.s0.cstride % 8 || p.s0.coff % 8 || p.out_cstride % 8 || p.out_coff % 8) return false;
   if (p.Ktot != p.Cin * (1 + (p.split ? 1 : 0)) || p.Kw < p.Ktot) return false;
   if ((long)p.B * p.Ho * p.Wo >= (1L << 30)) return false;
+  // the kernel moves 16 bytes per lane on every path (LDS-DMA pieces, weight rows, float4 bias, uint4 stores)
+  if ((((uintptr_t)p.s0.ptr | (uintptr_t)p.w | (uintptr_t)p.out) & 15) || (p.bias && ((uintptr_t)p.bias & 15)) || p.Kw % 8) return false;
   c.cinc = p.Cin / 32; c.kt = p.Ktot / 32;
   if (p.Cout == 256) c.wn = 8; else if (p.Cout == 128) c.wn = 4; else if (p.Cout == 64) c.wn = 2; else return false;
   // the instantiated shapes: (Cout, Cin, planes)
@@ -281,7 +283,9 @@ static bool stream_cfg(const ConvP& p, StreamCfg& c) {
 }
 bool conv_stream_legal(const ConvP& p) { StreamCfg c; return stream_cfg(p, c); }
 
-int g_stream_flags = 10;                               // cc_dev_set("stream_flags", bits): StreamAux::flags
+// cc_dev_set("stream_flags", bits): StreamAux::flags.  CLEARCAM_STREAM_FLAGS is read HERE, once, when the library is loaded, so that a later
+// cc_dev_set wins (a lazy read inside the launcher overwrote an earlier cc_dev_set on the first launch)
+int g_stream_flags = [] { const char* e = getenv("CLEARCAM_STREAM_FLAGS"); return e ? atoi(e) : 10; }();
 int g_stream_abl = 0;                                  // cc_dev_set("stream_abl", bits): timing ablations of the f16 256 -> 256 shapes (development)
 template <class T, int WN, int KT, int CINC, int NP, int ABL = 0, int LATE = 0> static void launch_stream_k(const ConvP& p, hipStream_t stream) {
   constexpr int PT = (8 / WN) * NP * 16;
@@ -313,8 +317,6 @@ template <class T> static void launch_stream_t(const ConvP& p, const StreamCfg& 
   CC_CHECK(!g_stream_abl, "timing ablations of the streaming kernel need a development build (-DCC_STREAM_ABLATIONS)");
 #endif
   // flags bit 4: the activation arithmetic in the memory phase (LATE) - A/B per shape (cc_dev_set("stream_flags"))
-  static const bool env_once = [] { if (const char* e = getenv("CLEARCAM_STREAM_FLAGS")) g_stream_flags = atoi(e); return true; }();
-  (void)env_once;
   const bool late = (g_stream_flags & 4) != 0;
   if (p.Cout == 256 && p.Cin == 256) {
     if (pl == 2) { if (late) launch_stream_k<T, 8, 16, 8, 4, 0, 1>(p, stream); else launch_stream_k<T, 8, 16, 8, 4>(p, stream); }

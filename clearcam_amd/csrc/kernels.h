@@ -9,15 +9,16 @@ namespace cc {
 // had and how many tiles the chip takes per round (resident blocks x CUs; the grid for persistent kernels).  Filled only while
 // g_note_launches is set - the occupancy query is not free.
 struct LaunchNote { const char* kernel; long tiles; long slots; };
-extern LaunchNote g_launch_note;
-extern bool g_note_launches;
+extern thread_local LaunchNote g_launch_note;   // per thread: cc_yolo_profile sets the switch and reads the note on the thread that launches
+extern thread_local bool g_note_launches;
 template <class K> inline void note_launch(const char* name, K kernel, long tiles, int threads, size_t lds, long persistent_grid = 0) {
   if (!g_note_launches) return;
   long slots = persistent_grid;
   if (!slots) {
-    int nb = 0, dev = 0; hipDeviceProp_t pr;
+    int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), threads, lds) != hipSuccess) nb = 1;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) slots = (long)nb * pr.multiProcessorCount;
+    static PerDevice pd;                                   // CU count cached per device (hipGetDeviceProperties is not cheap)
+    slots = (long)nb * pd.cu_count(pd.index());
   }
   g_launch_note = LaunchNote{name, tiles, slots > 0 ? slots : 1};
 }

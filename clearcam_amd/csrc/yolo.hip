@@ -1069,8 +1069,8 @@ bool streams_overlap(hipStream_t a, hipStream_t b) {
 // replaced until it overlaps with all of them; rejected streams stay alive until the end so that the runtime moves on to another
 // queue.  (Stream priority classes have queue pools of their own and would separate three slots by construction, but strict
 // priority only fills gaps: 10.7 ms per B = 64 detect step against 10.1 with three equal slots.)
-LaunchNote g_launch_note = {"", 0, 1};
-bool g_note_launches = false;
+thread_local LaunchNote g_launch_note = {"", 0, 1};
+thread_local bool g_note_launches = false;
 static std::mutex g_pool_mu;
 static std::map<int, std::deque<hipStream_t>> g_pool;
 hipStream_t pool_stream_get(int device, bool fresh) {
@@ -1560,15 +1560,23 @@ int cc_yolo_profile(cc_yolo* h, int iters, float* ms, double* alg_macs_per_step,
   for (auto& e : ev) CC_HIP(hipEventCreate(&e));
   double acc[5] = {0, 0, 0, 0, 0}, macs = 0; int nconv = 0;
   std::vector<cc::LaunchNote> notes(n, cc::LaunchNote{"", 0, 1});
+  if (getenv("CLEARCAM_PROFILE_CSV")) {
+    // the launch notes (kernel taken, tiles, slots: an occupancy query per launch) come from an UNTIMED pass of their own, so that
+    // no host work sits between the two events of a timed launch (pass 0 carried it and was summed into conv_ms / pool_ms)
+    for (size_t i = 0; i < n; ++i) {
+      cc::g_note_launches = true;
+      cc::g_launch_note = cc::LaunchNote{"", 0, 1};
+      launch_op(h->dtype, P, P->ops[i], s, true);
+      notes[i] = cc::g_launch_note;
+      cc::g_note_launches = false;
+    }
+    CC_HIP(hipStreamSynchronize(s));
+  }
   for (int it = 0; it < iters; ++it) {
     for (size_t i = 0; i < n; ++i) {
       const Op& op = P->ops[i];
       CC_HIP(hipEventRecord(ev[2 * i], s));
-      cc::g_note_launches = it == 0 && getenv("CLEARCAM_PROFILE_CSV");   // first pass only: the occupancy query sits between the events
-      cc::g_launch_note = cc::LaunchNote{"", 0, 1};
       launch_op(h->dtype, P, op, s, true);
-      if (it == 0) notes[i] = cc::g_launch_note;
-      cc::g_note_launches = false;
       CC_HIP(hipEventRecord(ev[2 * i + 1], s));
     }
     CC_HIP(hipStreamSynchronize(s));

@@ -286,6 +286,36 @@ def make_cameras(n: int, height: int = 1080, width: int = 1920, ring: Optional[i
     return [SyntheticCamera(height, width, seed=i, ring=ring, base=base) for i in range(n)]
 
 
+def natural_frames(n: int, height: int = 640, width: int = 640, seed: int = 0) -> np.ndarray:
+    """n uint8 BGR frames with the second-order statistics of camera images instead of white noise: a 1/f amplitude spectrum
+    (neighbouring pixels correlated at every scale), a flat region, and a dozen uniform rectangles with hard edges (the moving
+    rectangles of SyntheticCamera).  Parity / tail measurements use it beside the white-noise frames (all
+    detector evidence was white noise)."""
+    rng = np.random.default_rng(seed)
+    fy = np.fft.fftfreq(height)[:, None]
+    fx = np.fft.rfftfreq(width)[None, :]
+    amp = 1.0 / np.maximum(np.sqrt(fy * fy + fx * fx), 1.0 / max(height, width))
+    out = np.empty((n, height, width, 3), dtype=np.uint8)
+    for i in range(n):
+        spec = (rng.standard_normal((3, height, width // 2 + 1)) + 1j * rng.standard_normal((3, height, width // 2 + 1))) * amp
+        img = np.fft.irfft2(spec, s=(height, width))
+        img = (img - img.mean((1, 2), keepdims=True)) / img.std((1, 2), keepdims=True)
+        base = rng.uniform(70.0, 180.0)
+        contrast = rng.uniform(25.0, 60.0)
+        img = img * contrast + base
+        shade = 0.85 + 0.3 * (np.arange(width)[None, None, :] / width)            # a luminance gradient shared by the three channels
+        img = img * shade
+        frame = np.clip(img, 0, 255).transpose(1, 2, 0)
+        y0, x0 = int(rng.integers(0, height // 2)), int(rng.integers(0, width // 2))
+        frame[y0:y0 + height // 4, x0:x0 + width // 3] = rng.uniform(30, 220, 3)   # a flat region (wall, sky)
+        for _ in range(12):
+            h, w = int(rng.integers(16, height // 3)), int(rng.integers(16, width // 3))
+            y, x = int(rng.integers(0, height - h)), int(rng.integers(0, width - w))
+            frame[y:y + h, x:x + w] = rng.uniform(0, 255, 3)
+        out[i] = np.clip(np.rint(frame), 0, 255).astype(np.uint8)
+    return out
+
+
 def main() -> None:
     import argparse
     import json

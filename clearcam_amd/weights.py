@@ -197,8 +197,13 @@ COND_DFL_STD, COND_DFL_RAMP, COND_CLS_BIAS, COND_Q, COND_ACTIVE_CLASSES = 0.5, 0
 # pre-activations - a network that amplifies perturbations, between the benign checkpoint (f32 perturbation gain 1.4-2 from the input to
 # P3..P5) and the chaotic seeded one (30-60x).  name -> (COND_EPS, COND_STD); measured gains in assets/synth_cond_report.json:
 # "g3" 2.8 / 3.5 / 3.9 at P3 / P4 / P5, "g10" 8.1 / 11 / 13.
-COND_STRESS = {"g3": (1.0, 0.3), "g10": (1.0, 0.6)}
-COND_STRESS_CLS_SHIFT = {"g3": 0.4, "g10": 0.0}         # class-logit bias shift: g3's logits are narrow, without it 0-1 detections per frame
+COND_STRESS = {"g3": (1.0, 0.3), "g10": (1.0, 0.6),
+               # "nat" (round 6): the benign construction CALIBRATED ON NATURAL-STATISTICS FRAMES (clearcam_amd.streams.natural_frames: 1/f spectrum,
+               # flat regions, hard-edged rectangles) instead of white noise - the low-pass filters pass such frames un-attenuated, so the
+               # noise-calibrated tables overflow f16 on them; a trained network's normalisation is fitted to its data the same way
+               "nat": (COND_EPS, COND_STD)}
+COND_NATURAL = ("nat",)                                  # variants whose calibration / evaluation frames are natural_frames(...)
+COND_STRESS_CLS_SHIFT = {"g3": 0.4, "g10": 0.0, "nat": 0.6}         # class-logit bias shift: g3's logits are narrow, without it 0-1 detections per frame
 _BINOMIAL3 = (np.outer([1.0, 2.0, 1.0], [1.0, 2.0, 1.0]) / 16.0).astype(np.float32)
 _COND = {}
 

@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -16,10 +17,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the pool's driver only supports dmabuf IPC (RCCL across processes)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(3)
         E = rng.standard_normal((1000, 16)).astype(np.float32)
@@ -27,12 +33,13 @@ def _worker(rank, world, port, ret):
         q = rng.standard_normal((3, 16)).astype(np.float32)
         bounds = [0, 600, 1000]                              # ragged shards
         lo, hi = bounds[rank], bounds[rank + 1]
-        off, total = shard_offsets(hi - lo)
+        dev = torch.device("cuda", rank) if backend == "nccl" else None      # RCCL moves device tensors
+        off, total = shard_offsets(hi - lo, None, dev)
         assert (off, total) == (lo, 1000)
         k = 20
         sc = q @ E[lo:hi].T                                  # test scaffolding: the local scan runs in HIP in production
         order = np.argsort(-sc, axis=1, kind="stable")[:, :k]
-        gi, gs = allgather_topk(order, np.take_along_axis(sc, order, 1), off, k)
+        gi, gs = allgather_topk(order, np.take_along_axis(sc, order, 1), off, k, None, dev)
         full = q @ E.T
         ref = np.argsort(-full, axis=1, kind="stable")[:, :k]
         ok = np.array_equal(gi, ref) and np.allclose(gs, np.take_along_axis(full, ref, 1))
@@ -46,6 +53,18 @@ def test_sharded_topk_allgather_gloo_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get(0) is True and ret.get(1) is True
+
+
+@pytest.mark.gpu
+def test_sharded_topk_allgather_nccl_world2():
+    """The same exchange over RCCL, one rank per GPU: runs on the first box that has two GPUs (the pool's boxes have one: skipped there),
+    so that N > 1 over xGMI is exercised without further work."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret, "nccl"), nprocs=2, join=True)
     assert ret.get(0) is True and ret.get(1) is True
 
 

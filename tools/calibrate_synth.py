@@ -67,7 +67,14 @@ def calibrate(size: str, seed: int = 1234, res: int = 640):
 
 # ---- the well-conditioned checkpoint ---------------------------------------------------------------------------------
 
-def calibrate_conditioned(size: str, seed: int = 1234, res: int = 640, n_frames: int = 8, eps=None, std=None):
+def _frames(n: int, res: int, seed: int, natural: bool):
+    if natural:
+        from clearcam_amd.streams import natural_frames
+        return natural_frames(n, res, res, seed=seed)
+    return np.random.default_rng(seed).integers(0, 256, (n, res, res, 3), dtype=np.uint8)
+
+
+def calibrate_conditioned(size: str, seed: int = 1234, res: int = 640, n_frames: int = 8, eps=None, std=None, natural: bool = False):
     """-> table {"g:<conv>": gain (scalar, or per output channel in the head), "b:<conv>": bias shift per channel, "j:<conv>": jitter}.
     eps / std: the stress variants' share of white filter and pre-activation std (clearcam_amd.weights.COND_STRESS)."""
     o = YOLOv9Oracle(size, res, W.conditioned_base_weights(size, seed, eps))      # unit gains, the seeded N(0,1) bias draws
@@ -108,16 +115,16 @@ def calibrate_conditioned(size: str, seed: int = 1234, res: int = 640, n_frames:
         return orig(x, name, stride, groups)
 
     o._conv2d = hooked
-    fr = np.random.default_rng(7).integers(0, 256, (n_frames, res, res, 3), dtype=np.uint8)
+    fr = _frames(n_frames, res, 7, natural)
     with torch.no_grad():
         o.head_raw(o.features(o.network_input(fr)))
     return table
 
 
-def conditioning_report(size: str, sd, res: int = 640, n_frames: int = 12):
+def conditioning_report(size: str, sd, res: int = 640, n_frames: int = 12, natural: bool = False):
     """Measured properties of a checkpoint: f32 perturbation gains and the 16-bit storage emulation against the f32 oracle."""
     from oracle.lowprec_oracle import LowPrecOracle, rel_rms
-    frames = np.random.default_rng(1).integers(0, 256, (n_frames, res, res, 3), dtype=np.uint8)
+    frames = _frames(n_frames, res, 1, natural)
     o = YOLOv9Oracle(size, res, sd)
     rep = {"frames": n_frames, "res": res}
     with torch.no_grad():
@@ -178,10 +185,12 @@ if __name__ == "__main__":
         for size in sizes:
             tag = f"{size}_{stress}" if stress else (size if seed == 1234 else f"{size}_s{seed}")
             eps, std = W.COND_STRESS[stress] if stress else (None, None)
-            table = calibrate_conditioned(size, seed, eps=eps, std=std)
+            nat = stress in W.COND_NATURAL
+            table = calibrate_conditioned(size, seed, eps=eps, std=std, natural=nat)
             np.savez_compressed(os.path.join(ASSETS, f"synth_cond_{tag}.npz"), **W.pack_cond_table(size, table))
             W._COND.pop(tag, None)
-            report[tag] = conditioning_report(size, W.conditioned_yolov9_state_dict(size, seed, stress=stress))
+            report[tag] = conditioning_report(size, W.conditioned_yolov9_state_dict(size, seed, stress=stress), natural=nat)
+            report[tag]["frames"] = "natural_frames (1/f + flat regions + rectangles)" if nat else report[tag]["frames"]
             if stress:
                 report[tag]["stress"] = {"eps": eps, "preact_std": std}
             report[tag]["design"] = {"eps": W.COND_EPS, "preact_std": W.COND_STD, "dfl_std": W.COND_DFL_STD, "dfl_ramp": W.COND_DFL_RAMP, "cls_bias": W.COND_CLS_BIAS, "quantile": W.COND_Q, "active_classes": W.COND_ACTIVE_CLASSES}

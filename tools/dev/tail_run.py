@@ -2,7 +2,7 @@
 # conditioned checkpoints with un-rounded float32 weights.  Reference = the library's own f32 mode (pinned to the CPU oracle by
 # tests/test_gpu_yolo.py::test_conditioned_checkpoint_f32_mode and the f32 parity tests: boxes within 0.05 px, scores within 5e-5), so
 # that hundreds of frames fit into seconds; the parity TESTS keep using the CPU oracle.
-# argv: [frames] [modes, comma list of f16,f16h,f16s,f16c,f16c:noise,f16c:smooth,f16c:blocks] [seeds];  env CLEARCAM_CALIB_DAMP
+# argv: [frames] [modes, comma list of f16,f16h,f16s,f16c,f16c:noise,f16c:smooth,f16c:blocks] [seeds] [family: noise | natural];  env CLEARCAM_CALIB_DAMP
 import os, sys, numpy as np, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from clearcam_amd.weights import conditioned_yolov9_state_dict
@@ -10,7 +10,8 @@ from clearcam_amd.yolov9 import YOLOv9
 from oracle.yolov9_oracle import parity_summary, tolerance_bars
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 modes = (sys.argv[2] if len(sys.argv) > 2 else "f16,f16h,f16s,f16c,f16c:smooth,f16c:blocks").split(",")
-seeds = [x if x.startswith("g") else int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1234,7,99").split(",")]   # g3 / g10: the stress variants
+seeds = [x if not x.isdigit() else int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1234,7,99").split(",")]   # g3 / g10 / nat: the variants of clearcam_amd.weights.COND_STRESS
+family = sys.argv[4] if len(sys.argv) > 4 else "noise"              # natural: 1/f spectrum + flat regions + rectangles (clearcam_amd.streams.natural_frames)
 def cal(kind, n=4):
     fr = np.random.default_rng(4242).integers(0, 256, (n, 640, 640, 3), dtype=np.uint8)
     if kind == "smooth":
@@ -27,10 +28,15 @@ def run(m, fr):
         det.append(m.detect_batch(fr[i:i + 64])); dec.append(m.get_tensor("decoded"))
     return np.concatenate(det), np.concatenate(dec)
 keys = ("match_frac", "match_frac_clear_of_threshold", "anchor_box_err_px_p50", "anchor_box_err_px_p99", "anchor_box_err_px_p999", "anchor_box_err_px_max", "anchors_over_tol", "anchors_both_over_thr", "frames_with_anchors_over_tol", "worst_frame_share", "anchor_score_err_max")
-print(f"# {nf} white-noise frames per checkpoint, reference = this library's f32 mode, box tolerance 0.64 px; damp {os.environ.get('CLEARCAM_CALIB_DAMP', 'default')}")
+print(f"# {nf} {'white-noise' if family == 'noise' else '1/f + rectangles'} frames per checkpoint, reference = this library's f32 mode, box tolerance 0.64 px; damp {os.environ.get('CLEARCAM_CALIB_DAMP', 'default')}")
 for seed in seeds:
     sd = conditioned_yolov9_state_dict("c", 1234, exact=False, stress=seed) if isinstance(seed, str) else conditioned_yolov9_state_dict("c", seed, exact=False)
-    fr = np.random.default_rng(1000 + (1234 if isinstance(seed, str) else seed)).integers(0, 256, (nf, 640, 640, 3), dtype=np.uint8)
+    fseed = 1000 + (1234 if isinstance(seed, str) else seed)
+    if family == "natural" or seed == "nat":                         # the "nat" checkpoint is calibrated on such frames (the noise-calibrated tables overflow f16 on them)
+        from clearcam_amd.streams import natural_frames
+        fr = natural_frames(nf, 640, 640, seed=fseed)
+    else:
+        fr = np.random.default_rng(fseed).integers(0, 256, (nf, 640, 640, 3), dtype=np.uint8)
     m = YOLOv9("c", 640, state_dict=sd, dtype="f32"); ref, dec_ref = run(m, fr); m.close()
     for mode in modes:
         dt, _, kind = mode.partition(":")

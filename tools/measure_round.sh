@@ -4,6 +4,7 @@
 #   2 per-launch tables of the bench plan, B=64/1  -> gpurun_out/<tag>_yolo_per_launch.csv, <tag>_yolo_per_launch_b1.csv
 #   3 rocprofv3 --kernel-trace --stats, 10 replays, ONE batch in flight (no launch shares the chip with another) -> gpurun_out/<tag>_yolo_kernel_stats.csv (+ .txt summary)
 #   4 rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel trace only) -> gpurun_out/pmc_traffic.json, <tag>_pmc_traffic.txt
+#   5 rocprofv3 SQ pass (wave cycles, waits, VALU / LDS activity, bank conflicts, SQ_VALU_MFMA_BUSY_CYCLES) -> gpurun_out/<tag>_plan_sq.txt
 # The PMC record carries the digest of clearcam_amd/csrc; bench.py quotes it only while the digest matches, so run this on the final code
 # and run the bench LAST (step 1 is executed after step 4 for that reason).
 set -u
@@ -24,7 +25,7 @@ import csv, json, os, sys
 from bench import kernel_source_digest
 tag = sys.argv[1]
 rows = list(csv.DictReader(open(f"gpurun_out/{tag}_yolo_kernel_stats.csv")))
-fam = lambda n: "conv" if ("conv" in n or "csp_fused" in n) else "stem" if "stem_fused" in n else "pool" if "pool" in n else "other"   # noqa: E731
+from tools.kernel_family import family as fam
 tot = {}
 for r in rows:
     tot[fam(r["Name"])] = tot.get(fam(r["Name"]), 0.0) + float(r["TotalDurationNs"]) / 1e6
@@ -41,5 +42,7 @@ print(json.dumps(rec))
 PY
 (cd /tmp && python $root/tools/pmc_traffic.py $tag > $root/gpurun_out/${tag}_pmc.log 2>&1)
 cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json 2>/dev/null
+bash tools/dev/pmc_kernels.sh ${tag}_plan tools/dev/plan_passes.py 3 > gpurun_out/${tag}_sq_stdout.txt 2>&1      # the MFMA-busy table of the plan
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
+cp bench_detail.json gpurun_out/${tag}_bench_detail.json 2>/dev/null
 tail -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_pmc.log | cut -c1-400; head -12 gpurun_out/${tag}_yolo_${dt}_b64.txt

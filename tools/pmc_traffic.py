@@ -49,16 +49,16 @@ def main():
     replays = PASSES + 1
     # every conv kernel family (conv_mfma / conv_phase / conv_persist / conv_direct / 3x3 specialisations / fused RepNCSP); rocprofv3
     # leaves the _Float16 instantiations MANGLED (_ZN2cc19conv_persist_kernelIDF16_...), so match inside the name
-    is_conv = lambda k: (("conv" in k and "kernel" in k) or "csp_fused" in k) and "pool" not in k           # noqa: E731
+    from tools.kernel_family import family
     lines, conv_r, conv_w, pool_r, pool_w = [], 0.0, 0.0, 0.0, 0.0
     for k in sorted(set(fetch) | set(write)):
         r_b, w_b = 2.0 * fetch.get(k, 0.0) * 1024 / replays, write.get(k, 0.0) * 1024 / replays
         if "stem_fused" in k:
             r_b /= 2.0                                                         # dword loads of the uint8 frames: FETCH_SIZE taken as reported
         lines.append(f"{k[:100]:100} launches/step {fcalls.get(k, 0) / replays:7.1f}  read {r_b / 1e9:8.3f} GB  write {w_b / 1e9:8.3f} GB")
-        if is_conv(k):
+        if family(k) == "conv":
             conv_r += r_b; conv_w += w_b
-        elif "pool" in k:
+        elif family(k) == "pool":
             pool_r += r_b; pool_w += w_b
     dtype = os.environ.get("CLEARCAM_BENCH_DTYPE", "f16h")
     rec = {"kernel_source_digest": kernel_source_digest(), "tag": tag, "dtype": dtype, "config": f"YOLOv9-C {dtype} B=64 640x640", "plan_replays_per_pass": replays,
