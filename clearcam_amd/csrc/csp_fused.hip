@@ -451,10 +451,11 @@ void launch_csp_fused(int dt, const CspP& p0, hipStream_t stream) {
   // (tests: small batches, ragged tiles); read once per process
   static const int tile_mode = [] { const char* e = getenv("CLEARCAM_CSP_TILE"); return e ? atoi(e) : 1; }();
   const bool tile_on = tile_mode != 0;
-  // ... from two rounds of its 16 x 32 tiles on: below that (a single frame: 50 tiles) this file's 128-pixel tiles spread over more CUs.
+  // ... from one round of its 16 x 32 tiles on (256 tiles: B >= 6 at 160 x 160; measured a tie from 200 tiles and 1.6 % ahead at 400,
+  // profiles/r06n_csp_tile_threshold.txt): below that (a single frame: 50 tiles, +0.04 ms) this file's 128-pixel tiles spread over more CUs.
   // Both are bit-identical to the four launches they replace, so the choice may depend on the batch size.
   const long tiles32 = (long)p0.B * ((p0.H + 15) / 16) * ((p0.W + 31) / 32);
-  if (tile_on && !p0.stream && !p0.dbg && (tiles32 >= 512 || tile_mode == 2) && csp_tile_supported(dt, p0.hid, p0.split)) { launch_csp_tile(dt, p0, stream); return; }
+  if (tile_on && !p0.stream && !p0.dbg && (tiles32 >= 256 || tile_mode == 2) && csp_tile_supported(dt, p0.hid, p0.split)) { launch_csp_tile(dt, p0, stream); return; }
   CspP p = p0;
   p.tx = (p.W + 15) / 16; p.tiles = ((p.H + 7) / 8) * p.tx;
   p.inv_tiles = 1.0f / (float)p.tiles; p.inv_tx = 1.0f / (float)p.tx;

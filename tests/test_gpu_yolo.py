@@ -996,13 +996,13 @@ np.savez(out, **d)
 
 @pytest.mark.parametrize("size,res,dtype,H,W,B,level,fused", [
     # round 6: csp_tile_kernel (hidden width 32: weights resident in LDS in fragment order, 16 x 32 tiles, register-chained 1x1 convs) is taken
-    # from two rounds of tiles on (B >= 11 at 160 x 160); level "1t" / "2t" force it at these small batches (CLEARCAM_CSP_TILE=2)
+    # from one round of tiles on (256 tiles: B >= 6 at 160 x 160); level "1t" / "2t" force it at these small batches (CLEARCAM_CSP_TILE=2)
     ("c", 640, "bf16", 640, 640, 3, "1t", 2),     # one weight plane, bf16; three frames: blocks with one tile and blocks with none
     ("c", 640, "f16h", 640, 640, 1, "2t", 6),     # two planes in the 1x1 convs (68 KB of weights resident); 50 tiles on 48 blocks
     ("c", 608, "f16h", 608, 608, 2, "2t", 6),     # 152 x 152 maps: ragged 16 x 32 tiles on both axes
     ("c", 640, "f16", 270, 480, 2, "2t", 6),      # letterboxed 384 x 640: 96 x 160 maps
     ("m", 320, "f16", 320, 320, 2, "1t", 2),      # YOLOv9-m: hidden width 32 at 80 x 80
-    ("c", 640, "f16h", 640, 640, 12, "2", 6),     # 600 tiles: the kernel by its own rule
+    ("c", 640, "f16h", 640, 640, 6, "2", 6),      # 300 tiles: the kernel by its own rule
     ("c", 640, "bf16", 640, 640, 3, "1", 2),      # the bench plan's shapes: hidden width 32 at 160x160 (weights resident, persistent blocks)
     ("c", 640, "f16", 640, 640, 1, "2", 6),       # + hidden width 64 at 80x80 (weights streamed); a single frame: fewer tiles than CUs
     ("c", 608, "bf16", 608, 608, 2, "2", 6),      # 152 x 152 and 76 x 76 maps: ragged 8 x 16 tiles on both axes
