@@ -681,6 +681,8 @@ template <class T, int TS> static void launch_big(const ConvP& p, const ConvAux&
 }
 
 void launch_conv_phase(int dt, const ConvP& p, const ConvAux& a, int M, hipStream_t stream);   // conv_phase.hip
+bool conv_tile64_legal(const ConvP& p);                                                          // conv_tile64.hip
+void launch_conv_tile64(int dt, const ConvP& p, hipStream_t stream);
 bool conv_wave_legal(const ConvP& p);                                                            // conv_wave.hip
 void launch_conv_wave(int dt, const ConvP& p, hipStream_t stream);
 bool conv_stream_legal(const ConvP& p);                                                          // conv_stream.hip
@@ -860,6 +862,17 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
       if (wave_on < 0) { const char* e = getenv("CLEARCAM_WAVE"); wave_on = e ? atoi(e) : 1; }
       // measured (B=64): 64 -> 64 at 80x80 51 us vs 57 (weights-stationary) / 59 (generic), at 160x160 204 vs 223 / 262; 32 -> 32
       // ties the weights-stationary kernel (61 vs 58 us) and a handful of sub-tiles (batch 1) is better served by the tile kernels
+      // 64 -> 64 from one round of 8 x 32-pixel tiles on: the persistent tile kernel with resident fragment-order weights (conv_tile64.hip,
+      // round 6; CLEARCAM_TILE64=0 disables, tests force it with variant 12).  Same K order as every kernel here: same bits.
+      if constexpr (sizeof(T) == 2) {
+        static const int tile64_on = [] { const char* e = getenv("CLEARCAM_TILE64"); return e ? atoi(e) : 1; }();
+        const long tiles64 = (long)p.B * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32);
+        if (p.variant == 12 || (p.variant == 0 && tile64_on && conv_tile64_legal(p) && tiles64 >= 256)) {
+          CC_CHECK(conv_tile64_legal(p), "3x3 64 -> 64 tile kernel: shape not eligible");
+          launch_conv_tile64(TypeTag<T>::dt, p, stream);
+          return;
+        }
+      }
       const long subtiles = (long)p.B * ((p.Ho + 1) / 2) * ((p.Wo + 15) / 16);
       if (p.variant == 8 || (p.variant == 0 && wave_on && conv_wave_legal(p) && p.Cin == 64 && subtiles >= 4096)) {
         CC_CHECK(conv_wave_legal(p), "wave-autonomous 3x3: shape not eligible");

@@ -1140,6 +1140,7 @@ namespace cc { void set_error(const std::string& m) { g_err = m; } }
 namespace cc { extern int g_phase_flags_override; }   // conv_phase.hip
 namespace cc { extern int g_stream_flags; }           // conv_stream.hip
 namespace cc { extern int g_stream_abl; }             // conv_stream.hip
+namespace cc { extern int g_tile64_abl; }             // conv_tile64.hip
 namespace cc { extern int g_stream_override; }        // conv_mfma.hip: -1 = CLEARCAM_STREAM / default, 0 / 1 = streaming 1x1 kernel off / on
 
 extern "C" {
@@ -1762,6 +1763,7 @@ int cc_dev_set(const char* key, int value) {
   else if (std::string(key) == "stream") cc::g_stream_override = value;
   else if (std::string(key) == "stream_abl") cc::g_stream_abl = value;
   else if (std::string(key) == "stream_flags") cc::g_stream_flags = value;
+  else if (std::string(key) == "tile64_abl") cc::g_tile64_abl = value;
   else throw cc::Error(-22, std::string("cc_dev_set: unknown key ") + key);
   CC_API_END
 }
@@ -1804,6 +1806,12 @@ int cc_conv_bench(int dtype, int B, int H, int W, int Cin, int Cout, int k, int 
   CC_HIP(hipStreamSynchronize(s));
   float t = 0; CC_HIP(hipEventElapsedTime(&t, e0, e1));
   *ms = t / iters;
+  if (const char* e = getenv("CLEARCAM_BENCH_DUMP")) {   // dev: the 256 slack bytes behind the output (a kernel's timing ablation may leave cycle counts there)
+    unsigned long long v[32] = {};
+    (void)e;
+    CC_HIP(hipMemcpy(v, out + nout * 2, sizeof(v), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 32; ++i) fprintf(stderr, "%llu%c", v[i], (i & 3) == 3 ? '\n' : ' ');
+  }
   hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
   hipFree(x); hipFree(out); hipFree(pc.w); hipFree(pc.bias);
   CC_API_END

@@ -237,6 +237,39 @@ def test_stream_1x1_equals_generic(case, act, dtype):
     assert float((got - ref).abs().max() / ref.abs().max()) <= tol
 
 
+# (name, B, H, W): the persistent 3x3 64 -> 64 tile kernel (conv_tile64.hip, variant 12)
+TILE64_CASES = [
+    ("two_rounds", 8, 64, 64),                            # 128 tiles on 128 blocks
+    ("long", 24, 80, 96),                                 # 720 tiles: several per block, both patch buffers, stores under the next K loop
+    ("ragged", 3, 13, 41),                                # ragged 8 x 32 tiles on both axes, blocks without a tile
+    ("one_tile", 1, 8, 32),
+    ("narrow", 2, 40, 7),                                 # maps narrower than a fragment
+]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("act", [1, 0])
+@pytest.mark.parametrize("case", TILE64_CASES, ids=[c[0] for c in TILE64_CASES])
+def test_tile64_3x3_equals_generic(case, act, dtype):
+    """Variant 12 (weights resident in LDS in fragment order, double-buffered 10 x 34 patches, hand-pipelined taps, accumulator rows permuted
+    for 16-byte stores) against torch and, bit for bit, against the generic tile kernel: same MFMA, same (tap, channel) walk, same epilogue."""
+    _, B, H, W_ = case
+    g = torch.Generator().manual_seed(hash(case[0]) % 1000 + act)
+    x = torch.randn(B, 64, H, W_, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(64, generator=g) * 0.1
+    got = conv_hip(x, w, b, 1, 1, act, dtype, force_direct=12)
+    generic = conv_hip(x, w, b, 1, 1, act, dtype, force_direct=2)
+    assert torch.equal(got, generic)
+    ref = F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b, padding=1)
+    if act:
+        ref = F.silu(ref)
+    assert float((got - ref).abs().max() / ref.abs().max()) <= TOL[dtype]
+    # the grouped form DDetect's box branch uses (four groups, densified to block-diagonal weights by the caller)
+    wg = torch.randn(64, 16, 3, 3, generator=g) / 12.0
+    assert torch.equal(conv_hip(x, wg, b, 1, 4, act, dtype, force_direct=12), conv_hip(x, wg, b, 1, 4, act, dtype, force_direct=2))
+
+
 def test_detect_same_bits_with_and_without_stream_kernel():
     """The detector with the streaming 1x1 kernel on (default) and off (cc_dev_set("stream", 0)): identical rows in every storage mode -
     the kernel reads channel-slice views of the Concat buffers there, which the single-layer entry does not exercise."""
