@@ -40,9 +40,10 @@ namespace cc {
 // NS = LDS stages: the DMA of step t+NS-1 is issued while step t computes (prefetch distance NS-1 steps).
 // BM = pixels per tile (128 -> 4 waves, 256 -> 8 waves: half the L2->LDS weight traffic per flop).
 // (A ping-pong schedule and a register-staged loader were measured and dropped: DESIGN.md §4.)
-template <class T, int BM, int BN, int WM, bool SIMPLE, int CPRW, int NS>
-__global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const ConvAux a) {
-  constexpr int NT = 2 * BM, WN = NT / 64 / WM;
+// NTH = threads per block: 2 * BM by default; the few-tile configuration runs 64-pixel tiles on 256 threads (half the DMA issues per wave and step).
+template <class T, int BM, int BN, int WM, bool SIMPLE, int CPRW, int NS, int NTH = 2 * BM>
+__global__ __launch_bounds__(NTH) void conv_mfma_kernel(const ConvP p, const ConvAux a) {
+  constexpr int NT = NTH, WN = NT / 64 / WM;
   constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
   constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = CPRW * E;             // elements per K step
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(2 * BM) void conv_mfma_kernel(const ConvP p, const 
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
-  conv_epilogue<T, BM, BN, WM, MI, NJ>(p, acc, n0, lds, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; });
+  conv_epilogue<T, BM, BN, WM, MI, NJ, NT>(p, acc, n0, lds, [&](int row) { const int m = m0 + row; return m < M ? (long)m : -1L; });
 }
 
 // ---- 256 x 256 tile, four waves of 128 x 128: the schedule for wide, deep GEMM-shaped layers ---------------------------------
@@ -638,16 +639,16 @@ bool conv_mfma_supported(int dt, const ConvP& p) {
 // (bm: 128|256 pixels per tile, ns: 2|3 stages).
 static int g_cfg[4] = {-1, 0, 0, 0};
 
-template <class T, int BM, int BN, int WM, bool SIMPLE, int CPRW, int NS>
+template <class T, int BM, int BN, int WM, bool SIMPLE, int CPRW, int NS, int NTH = 2 * BM>
 static void launch_k(const ConvP& p, const ConvAux& a, int mtiles, hipStream_t stream) {
   constexpr size_t lds = (size_t)NS * (BM + BN) * CPRW * 16;
   static PerDevice once;                               // the attribute is per device (common.h)
   if (once.first(once.index())) {
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>),
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS, NTH>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  note_launch(BM == 256 ? "conv_mfma_256" : "conv_mfma_128", conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>, (long)mtiles * a.nt, 2 * BM, lds);
-  hipLaunchKernelGGL((conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS>), dim3(mtiles * a.nt), dim3(2 * BM), lds, stream, p, a);
+  note_launch(BM == 256 ? "conv_mfma_256" : (BM == 64 ? "conv_mfma_64" : (BM == 32 ? "conv_mfma_32" : "conv_mfma_128")), conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS, NTH>, (long)mtiles * a.nt, NTH, lds);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, BM, BN, WM, SIMPLE, CPRW, NS, NTH>), dim3(mtiles * a.nt), dim3(NTH), lds, stream, p, a);
 }
 
 static int g_thin_k = -1;     // K (elements) at or below which the 64-byte-row / 5-blocks-per-CU variant is used
@@ -818,6 +819,33 @@ template <class T> static bool launch_small(const ConvP& p, int M, hipStream_t s
   if (!bn) return false;
   bool deep = bn == 32 && b32 <= 256;                  // at most one block per CU anyway: six stages (120 KB), prefetch distance five
   if (p.variant >= 91 && p.variant <= 93) { bn = p.variant == 93 ? 64 : 32; deep = p.variant == 92; }   // tuning sweeps: 91 32/4, 92 32/6, 93 64/3
+  {   // Round 6: smaller pixel tiles on 256 threads for the layers of a single frame.  A K step of the 128 x 32 configuration costs ~0.43 us however
+      // deep the prefetch: five LDS-DMA issues per wave (60-100 cycles each), two dependent fragment-read batches, one barrier - and a 40 x 40
+      // layer is 104 blocks on 256 CUs.  32 x 32 tiles: one pixel + one weight DMA per wave and step, four times the blocks; 64 x 32: three
+      // DMAs, twice the blocks.  Measured per shape at batch 1 (profiles/r06r_small_tiles_b1.txt, cc_conv_bench): 3x3 256 -> 256 at 40 x 40
+      // 18.2 -> 13.3 us, 3x3 512 -> 64 at 20 x 20 29.2 -> 17.8, 1x1 256 -> 256 at 40 x 40 5.0 -> 3.5; the sum over the 103 launches 1087 -> ~800 us.
+      // 32 x 32 up to 800 blocks, 64 x 32 up to 512; six stages for K >= 4096 on 32 x 32, four otherwise.  CLEARCAM_SMALL_PIX=0 disables;
+      // tests force them with variants 94-97.  Same K order and MFMA as every tile kernel: same bits, so the batch a frame arrives in does not matter.
+    static const int small_pix = [] { const char* e = getenv("CLEARCAM_SMALL_PIX"); return e ? atoi(e) : 1; }();
+    const long n32 = (p.Cout + 31) / 32, t32 = (long)((M + 31) / 32) * n32, t64 = (long)((M + 63) / 64) * n32;
+    int pix = 0, st = 4;
+    if (p.variant == 0 && small_pix) { if (t32 <= 800) { pix = 32; st = p.Ktot >= 4096 ? 6 : 4; } else if (t64 <= 512) pix = 64; }
+    if (p.variant == 94) { pix = 64; st = 6; } else if (p.variant == 95) pix = 64; else if (p.variant == 96) { pix = 32; st = 6; } else if (p.variant == 97) pix = 32;
+    if (pix) {
+      ConvAux a{};
+      a.nt = (int)n32;
+      a.inv_hw = 1.0f / (float)(p.Ho * p.Wo); a.inv_wo = 1.0f / (float)p.Wo;
+      const bool simple = p.s1.C == 0 && p.s0.shift == 0 && p.ks <= 3;
+      a.is1x1 = simple && p.ks == 1 && p.stride == 1 && p.pad == 0 && p.Hin == p.Ho && p.Win == p.Wo;
+      const int mt64 = (M + 63) / 64, mt32 = (M + 31) / 32;
+      if (pix == 32 && st == 6) { if (simple) launch_k<T, 32, 32, 2, true, 8, 6, 256>(p, a, mt32, stream); else launch_k<T, 32, 32, 2, false, 8, 6, 256>(p, a, mt32, stream); }
+      else if (pix == 32) { if (simple) launch_k<T, 32, 32, 2, true, 8, 4, 256>(p, a, mt32, stream); else launch_k<T, 32, 32, 2, false, 8, 4, 256>(p, a, mt32, stream); }
+      else if (st == 6) { if (simple) launch_k<T, 64, 32, 4, true, 8, 6, 256>(p, a, mt64, stream); else launch_k<T, 64, 32, 4, false, 8, 6, 256>(p, a, mt64, stream); }
+      else { if (simple) launch_k<T, 64, 32, 4, true, 8, 4, 256>(p, a, mt64, stream); else launch_k<T, 64, 32, 4, false, 8, 4, 256>(p, a, mt64, stream); }
+      CC_HIP(hipGetLastError());
+      return true;
+    }
+  }
   ConvAux a{};
   a.nt = (p.Cout + bn - 1) / bn;
   a.inv_hw = 1.0f / (float)(p.Ho * p.Wo); a.inv_wo = 1.0f / (float)p.Wo;
@@ -855,7 +883,7 @@ template <class T> static void launch_t(const ConvP& p, hipStream_t stream) {
     }
     const bool few_narrow = p.variant == 0 && ws_legal(p) && (long)((M + 127) / 128) * ((p.Cout + 31) / 32) <= 512;
     if (few_narrow) { launch_ws_t<T>(p, stream); CC_HIP(hipGetLastError()); return; }
-    if (((p.variant == 0 && !halo_applicable(p)) || p.variant == 9 || (p.variant >= 91 && p.variant <= 93)) && launch_small<T>(p, M, stream, p.variant >= 9)) return;
+    if (((p.variant == 0 && !halo_applicable(p)) || p.variant == 9 || (p.variant >= 91 && p.variant <= 97)) && launch_small<T>(p, M, stream, p.variant >= 9)) return;
     {   // narrow 3x3 layers: one autonomous wave per 2x16-pixel sub-tile over LDS-resident weights (conv_wave.hip).
         // CLEARCAM_WAVE=0 falls back to the cooperative kernels below; tests force it with variant 8.
       static int wave_on = -1;

@@ -189,8 +189,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[NJ][M
       __syncthreads();
       T* outp = reinterpret_cast<T*>(p.out) + p.out_coff + n0;
 #pragma unroll
-      for (int q = 0; q < BM * CPR / NT; ++q) {
+      for (int q = 0; q < (BM * CPR + NT - 1) / NT; ++q) {
         const int idx = tid + NT * q, row = idx / CPR, ch = idx - row * CPR;
+        if ((BM * CPR) % NT != 0 && idx >= BM * CPR) break;   // tiles with fewer 16-byte chunks than threads (32 x 32 on 256 threads)
         const long m = pix(row);
         if (m >= 0 && n0 + ch * 8 < p.Cout)
           *reinterpret_cast<uint4*>(outp + (size_t)m * p.out_cstride + ch * 8) =
