@@ -457,10 +457,19 @@ struct Builder {
     static const bool dev = [] { const char* e = getenv("CLEARCAM_DEV"); return e && atoi(e) != 0; }();
     return dev ? getenv(name) : nullptr;
   }
+  // Round 6: at hidden width 64 the layer-at-a-time path has caught up wherever conv_tile64.hip takes the block's two 3x3 64 -> 64 convs (one round of its
+  // 8 x 32 tiles: B >= 9 at 80x80, unsplit 3x3 weights) - whole step, B = 64, f16h, twice each: 6582 / 6582 frames/s against 6531 / 6452 fused
+  // (profiles/r06x_fuse_csp.txt).  Level 2 (default) therefore fuses hidden 64 only below that; 3 = always (the round-2..5 behaviour).  Both forms
+  // produce the same bits (test_fused_csp_equals_unfused), so the choice may depend on the batch.
   bool fuse_csp(View in, int hid, int index, const std::string& r) {
     const char* e = getenv("CLEARCAM_FUSE_CSP");
     const int level = e ? atoi(e) : 2;
     if (level == 0 || (level == 1 && hid != 32)) return false;
+    if (level == 2 && hid == 64 && !pconv({r + ".m.list.0.cv1.conv"}, {1}).split) {
+      const Buf& ib = P->bufs[in.buf];
+      const char* t64 = getenv("CLEARCAM_TILE64");
+      if (!(t64 && atoi(t64) == 0) && (long)P->B * ((ib.H + 7) / 8) * ((ib.W + 31) / 32) >= 256) return false;
+    }
     const char* only = dev_env("CLEARCAM_CSP_ONLY");                // development: fuse just this block (csp_debug.py)
     if (only && atoi(only) != index) return false;
     if (!(a.rep_n == 1 && csp_fused_supported(Y->dtype, hid, Y->wsplit) && in.C == 2 * hid && in.coff % 8 == 0 && P->bufs[in.buf].C % 8 == 0)) return false;

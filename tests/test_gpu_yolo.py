@@ -1064,6 +1064,8 @@ np.savez(out, **d)
     ("c", 608, "f16s", 608, 608, 2, "2", 6),      # ... ragged tiles
     ("c", 640, "f16h", 640, 640, 1, "2", 6),      # round 5: two planes in the 1x1 convs only (the four backbone blocks), one plane everywhere (the two neck blocks)
     ("c", 608, "f16h", 608, 608, 2, "2", 6),      # ... ragged tiles
+    ("c", 640, "f16h", 640, 640, 10, "2", 2),     # round 6: from one round of conv_tile64's tiles on (B >= 9 at 80 x 80) level 2 leaves hidden width 64 to the four launches ...
+    ("c", 640, "f16h", 640, 640, 10, "3", 6),     # ... level 3 fuses it at every batch size
 ])
 def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fused):
     """csp_fused_kernel (cv1|cv2, RepConvN 3x3, 3x3 + shortcut, cv3 of a RepNCSP in one launch, intermediates in LDS) against the
