@@ -25,6 +25,7 @@
 //  * wave w of a group owns output rows 2w, 2w + 1 of the tile (2 x 2 pixel fragments x four channel fragments = 64 accumulator registers);
 //  * MFMA row i of fragment pair (2s, 2s+1) is channel 32s + (i >> 2) * 8 + h * 4 + (i & 3), so a lane ends up with eight consecutive
 //    channels of its pixel: bias + activation in registers, ONE 16-byte store per 32 channels;
+//  * a 16-bit residual (the bottleneck's shortcut) is read as one 16-byte piece per 8 channels at the start of the finish phase and added after the activation;
 //  * a wave waits for its share of the next patch (vmcnt(0)) BEFORE it issues its output stores - those are never waited for on their
 //    own (the next vmcnt(0) of the wave is a whole K loop later).
 // K order (tap, 32-channel step) is that of every other conv kernel: same bits (tests/test_gpu_yolo.py::test_tile64_3x3_equals_generic).
@@ -199,6 +200,26 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[r][i][j]));
       } else if (pi >= 0 && pi < ng) {
         uint4 ov[2][2][2];                                           // [row][pixel fragment][channel half]
+        int b, h0, w0; tile_origin(tile_of(pi), b, h0, w0);
+        // the shortcut of a RepNBottleneck (detection/yolov9.py:82-89: x + cv2(cv1(x))): the residual's 16-byte pieces are requested now and
+        // added after the activation arithmetic, when they have long landed.  Same order as every other epilogue: act(fma(acc, scale, bias)) + r.
+        uint4 rv[2][2][2];
+        if (p.res) {
+          const T* resp = reinterpret_cast<const T*>(p.res) + p.res_coff + fg * 8;
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int ho = h0 + 2 * wg + r, wo = w0 + 16 * i + fr;
+              const bool ok = ho < p.Ho && wo < p.Wo;
+              const T* src = resp + (((size_t)b * p.Ho + (ok ? ho : 0)) * p.Wo + (ok ? wo : 0)) * (size_t)p.res_cstride;
+              rv[r][i][0] = *reinterpret_cast<const uint4*>(src); rv[r][i][1] = *reinterpret_cast<const uint4*>(src + 32);
+            }
+        }
+        auto add2 = [](float a0, float a1, unsigned rr) -> unsigned {   // two activated values + the two residual values packed in rr
+          const T* t = reinterpret_cast<const T*>(&rr);
+          return pack2<T>(to_f32<T>(t[0]) + a0, to_f32<T>(t[1]) + a1);
+        };
         auto outputs = [&](auto act_tag) {
           constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
@@ -209,11 +230,17 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
 #pragma unroll
               for (int i = 0; i < 2; ++i) {
                 const f32x4 lo = acc[r][i][2 * s2], hi = acc[r][i][2 * s2 + 1];
+                const float v0 = activate<T, ACT>(__builtin_fmaf(lo[0], osc, b0.x)), v1 = activate<T, ACT>(__builtin_fmaf(lo[1], osc, b0.y));
+                const float v2 = activate<T, ACT>(__builtin_fmaf(lo[2], osc, b0.z)), v3 = activate<T, ACT>(__builtin_fmaf(lo[3], osc, b0.w));
+                const float v4 = activate<T, ACT>(__builtin_fmaf(hi[0], osc, b1.x)), v5 = activate<T, ACT>(__builtin_fmaf(hi[1], osc, b1.y));
+                const float v6 = activate<T, ACT>(__builtin_fmaf(hi[2], osc, b1.z)), v7 = activate<T, ACT>(__builtin_fmaf(hi[3], osc, b1.w));
                 uint4 o;
-                o.x = pack2<T>(activate<T, ACT>(__builtin_fmaf(lo[0], osc, b0.x)), activate<T, ACT>(__builtin_fmaf(lo[1], osc, b0.y)));
-                o.y = pack2<T>(activate<T, ACT>(__builtin_fmaf(lo[2], osc, b0.z)), activate<T, ACT>(__builtin_fmaf(lo[3], osc, b0.w)));
-                o.z = pack2<T>(activate<T, ACT>(__builtin_fmaf(hi[0], osc, b1.x)), activate<T, ACT>(__builtin_fmaf(hi[1], osc, b1.y)));
-                o.w = pack2<T>(activate<T, ACT>(__builtin_fmaf(hi[2], osc, b1.z)), activate<T, ACT>(__builtin_fmaf(hi[3], osc, b1.w)));
+                if (p.res) {
+                  const uint4 q = rv[r][i][s2];
+                  o.x = add2(v0, v1, q.x); o.y = add2(v2, v3, q.y); o.z = add2(v4, v5, q.z); o.w = add2(v6, v7, q.w);
+                } else {
+                  o.x = pack2<T>(v0, v1); o.y = pack2<T>(v2, v3); o.z = pack2<T>(v4, v5); o.w = pack2<T>(v6, v7);
+                }
                 ov[r][i][s2] = o;
               }
           }
@@ -222,7 +249,6 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
         if constexpr (ABL & 128) ts[1] += __builtin_readcyclecounter() - t0;
         wait_vmcnt<0>();                                             // the next patch (this wave's pieces) and the stores of the tile before
         if constexpr (ABL & 128) ts[2] += __builtin_readcyclecounter() - t0;
-        int b, h0, w0; tile_origin(tile_of(pi), b, h0, w0);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int ho = h0 + 2 * wg + r;
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
 
 bool conv_tile64_legal(const ConvP& p) {
   return !p.split && p.ks == 3 && p.stride == 1 && p.pad == 1 && p.s1.C == 0 && p.s0.shift == 0 && p.Cin == 64 && p.Cout == 64 && p.s0.C == 64 &&
-         p.Hin == p.Ho && p.Win == p.Wo && !p.res && !p.out_f32 && p.act <= 1 && !p.slope && p.Kw >= 576 && p.Kw % 8 == 0 &&
+         p.Hin == p.Ho && p.Win == p.Wo && (!p.res || (!p.res_f32 && p.res_cstride % 8 == 0 && p.res_coff % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) && !p.out_f32 && p.act <= 1 && !p.slope && p.Kw >= 576 && p.Kw % 8 == 0 &&
          p.s0.cstride % 8 == 0 && p.s0.coff % 8 == 0 && p.out_cstride % 8 == 0 && p.out_coff % 8 == 0 &&
          (((uintptr_t)p.s0.ptr | (uintptr_t)p.w | (uintptr_t)p.out) & 15) == 0 &&
          (long)p.B * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32) < (1L << 22);

@@ -1089,6 +1089,24 @@ def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fu
     assert np.abs(a["p3"]).max() > 0.05 and np.isfinite(a["p3"]).all()
 
 
+def test_tile64_in_the_detector_same_bits(tmp_path):
+    """The persistent 3x3 64 -> 64 tile kernel inside the detector (ten frames: one round of its tiles at 80 x 80 and 160 x 160), layer at a time so that
+    it also takes the RepNBottleneck convs that carry the shortcut (16-bit residual added after the activation), against the same plan with
+    CLEARCAM_TILE64=0 (wave-autonomous kernel, register epilogue): block outputs, P3-P5 and detections identical."""
+    import subprocess
+    import sys
+    outs = []
+    for t64 in ("0", "1"):
+        path = str(tmp_path / f"t64_{t64}.npz")
+        env = dict(os.environ, CLEARCAM_TILE64=t64, CLEARCAM_FUSE_CSP="0", CLEARCAM_TAP_CSP="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", _CSP_SCRIPT, "c", "640", "f16h", "640", "640", "10", path], check=True, env=env)
+        outs.append(np.load(path))
+    a, b = outs
+    for n in [n for n in a.files if n.startswith("csp")] + ["p3", "p4", "p5", "det"]:
+        assert np.array_equal(a[n], b[n]), n
+    assert (a["det"][..., 4] > 0).sum() > 10
+
+
 def test_pool_rows_per_thread_same_bits(tmp_path):
     """ADown's pools with eight / four output rows per thread (2x2 average; the avg-max kernel takes two) against one row per thread
     (CLEARCAM_POOL_ROWS, read once per process): every output sums its taps in the same order, so features and detections are IDENTICAL -
