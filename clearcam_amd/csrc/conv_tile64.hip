@@ -3,7 +3,7 @@
 //
 // conv3x3_wave_kernel (one autonomous wave per 2 x 16 strip) runs these at 645 TFLOP/s: 6 ds_reads per 8 MFMAs with per-read swizzle
 // arithmetic, a 2.25x patch over-read per strip, 8-byte stores.  Here a persistent block of eight waves works as TWO GROUPS of four, each
-// with its own stream of 8 x 32-pixel tiles, half a tile out of phase:
+// with its own stream of 256-pixel tiles (16 x 16, or 8 x 32 where that covers the map with fewer), half a tile out of phase:
 //  * the 72 KB of weights stay in LDS for the life of the block in MFMA-FRAGMENT ORDER (one 1 KB image per (k step, 16-row fragment):
 //    an A operand is one conflict-free ds_read_b128 at a compile-time offset), shared by both groups;
 //  * each group owns ONE 43.5 KB buffer for the 10 x 34 input patch of its tile (halo 1; zero page outside the image): 128-byte pixel rows
@@ -42,8 +42,11 @@ template <int N, class F> __device__ __forceinline__ void sfor64(F&& f) { sfor64
 
 struct Tile64Aux { float inv_tiles, inv_tx; int tiles, tx, total; };
 
-struct Tile64Geom {
-  static constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, PR = PH * PW;          // 10 x 34 = 340 patch pixels
+// TWIDTH = 32: 8 x 32-pixel tiles (a wave of a group owns 2 rows x 2 fragments); 16: 16 x 16 (4 rows x 1 fragment) - for maps whose width 32 does not
+// divide: an 80 x 80 map is 25 tiles of 16 x 16 against 30 of 8 x 32.  Same 256 pixels, same MFMAs and reads per wave, 324 patch pixels instead of 340.
+template <int TWIDTH> struct Tile64Geom {
+  static constexpr int TW = TWIDTH, TH = 256 / TW, PH = TH + 2, PW = TW + 2, PR = PH * PW;   // 10 x 34 = 340 / 18 x 18 = 324 patch pixels
+  static constexpr int RW = TH / 4, FW = TW / 16;                                         // rows and 16-pixel fragments per row of one wave
   static constexpr int NPIECE = (PR * 8 + 63) / 64;                                       // 43 DMA pieces of 1 KB (64 lanes x 16 B)
   static constexpr int PPW = (NPIECE + 3) / 4;                                            // pieces per wave of a group: 11
   static constexpr int PATCH_BYTES = NPIECE * 1024;                                       // 44 032
@@ -57,10 +60,12 @@ struct Tile64Geom {
 // are kept alive), 64 = fragment reads two k steps ahead instead of one, 256 = the K loop at priority 1,
 // 512 / 1024 = the finish phase at priority 3 while it requests the patch / at priority 1 throughout, 128 = cycle counts per phase kind behind the output.
 int g_tile64_abl = 0;
+int g_tile64_w = -1;
 
-template <class T, int ABL = 0>
+template <class T, int ABL = 0, int TWIDTH = 32>
 __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, const Tile64Aux a) {
-  using G = Tile64Geom;
+  using G = Tile64Geom<TWIDTH>;
+  constexpr int RW = G::RW, FW = G::FW;
   constexpr int PW = G::PW;
   static_assert(sizeof(T) == 2, "16-bit storage");
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
 
   unsigned long long tk = 0, tf = 0, tb = 0, t_start = 0;            // ABL 128: cycles in compute / finish / barrier, written behind the output by block 0
   if constexpr (ABL & 128) t_start = __builtin_readcyclecounter();
-  f32x4 acc[2][2][4];                                                // [row][pixel fragment][channel fragment]: written by a compute phase, read by the next finish phase
+  f32x4 acc[RW][FW][4];                                                // [row][pixel fragment][channel fragment]: written by a compute phase, read by the next finish phase
   unsigned long long ts[3] = {0, 0, 0};                              // ABL 128: inside the finish phases - until the patch is requested / the outputs are packed / the patch has landed
   const int nph = n + 1;                                             // group g computes its tile `it` in phase 2 it + g and finishes it in phase 2 it + g + 1
   for (int ph = 0; ph < nph; ++ph) {
@@ -146,23 +151,23 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
       // ---- compute: the K loop of tile `it` ------------------------------------------------------------------------------------------
       if (it < ng && !(ABL & 16)) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < FW; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[r][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int q0 = (2 * wg) * PW + fr;                           // patch pixel of tap (0, 0), row 0, fragment 0
+        const int q0 = (RW * wg) * PW + fr;                           // patch pixel of tap (0, 0), row 0, fragment 0
         auto pix_addr = [&](int q, int c) { const int v = q * 128 + c * 16; return pbase + (v ^ ((v >> 3) & 0x60)); };
         constexpr int PD = (ABL & 64) ? 2 : 1, NB = PD + 1;         // fragment reads run PD k steps ahead of the MFMAs that use them
-        uint4 xf[NB][2][2], wf[NB][4];
+        uint4 xf[NB][RW][FW], wf[NB][4];
         auto rd = [&](auto ks_c) {
           constexpr int KS = decltype(ks_c)::value, BUF = KS % NB, TAP = KS >> 1, KH = KS & 1, R = TAP / 3, S = TAP - R * 3;
 #pragma unroll
           for (int j = 0; j < 4; ++j) wf[BUF][j] = *reinterpret_cast<const uint4*>(ldsb + G::OFF_W + (KS * 4 + j) * 1024 + lane * 16);
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
+          for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xf[BUF][r][i] = *reinterpret_cast<const uint4*>(ldsb + pix_addr(q0 + (r + R) * PW + S + 16 * i, 4 * KH + fg));
+            for (int i = 0; i < FW; ++i) xf[BUF][r][i] = *reinterpret_cast<const uint4*>(ldsb + pix_addr(q0 + (r + R) * PW + S + 16 * i, 4 * KH + fg));
         };
         sfor64<PD>([&](auto k_c) { rd(k_c); });
         if constexpr (ABL & 256) __builtin_amdgcn_s_setprio(1);
@@ -171,9 +176,9 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
           if constexpr (KS + PD < G::NKS) rd(ICv<KS + PD>{});
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
+          for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < FW; ++i)
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 if constexpr (ABL & 8) asm volatile("" :: "v"(wf[CUR][j].x), "v"(wf[CUR][j].w), "v"(xf[CUR][r][i].x), "v"(xf[CUR][r][i].w));
@@ -193,24 +198,24 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
       if constexpr (ABL & 128) ts[0] += __builtin_readcyclecounter() - t0;
       if constexpr (ABL & 32) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < FW; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[r][i][j]));
       } else if (pi >= 0 && pi < ng) {
-        uint4 ov[2][2][2];                                           // [row][pixel fragment][channel half]
+        uint4 ov[RW][FW][2];                                           // [row][pixel fragment][channel half]
         int b, h0, w0; tile_origin(tile_of(pi), b, h0, w0);
         // the shortcut of a RepNBottleneck (detection/yolov9.py:82-89: x + cv2(cv1(x))): the residual's 16-byte pieces are requested now and
         // added after the activation arithmetic, when they have long landed.  Same order as every other epilogue: act(fma(acc, scale, bias)) + r.
-        uint4 rv[2][2][2];
+        uint4 rv[RW][FW][2];
         if (p.res) {
           const T* resp = reinterpret_cast<const T*>(p.res) + p.res_coff + fg * 8;
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
+          for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const int ho = h0 + 2 * wg + r, wo = w0 + 16 * i + fr;
+            for (int i = 0; i < FW; ++i) {
+              const int ho = h0 + RW * wg + r, wo = w0 + 16 * i + fr;
               const bool ok = ho < p.Ho && wo < p.Wo;
               const T* src = resp + (((size_t)b * p.Ho + (ok ? ho : 0)) * p.Wo + (ok ? wo : 0)) * (size_t)p.res_cstride;
               rv[r][i][0] = *reinterpret_cast<const uint4*>(src); rv[r][i][1] = *reinterpret_cast<const uint4*>(src + 32);
@@ -226,9 +231,9 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
           for (int s2 = 0; s2 < 2; ++s2) {
             const float4 b0 = *reinterpret_cast<const float4*>(ldsb + G::OFF_BIAS + s2 * 128 + fg * 32), b1 = *reinterpret_cast<const float4*>(ldsb + G::OFF_BIAS + s2 * 128 + fg * 32 + 16);
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < RW; ++r)
 #pragma unroll
-              for (int i = 0; i < 2; ++i) {
+              for (int i = 0; i < FW; ++i) {
                 const f32x4 lo = acc[r][i][2 * s2], hi = acc[r][i][2 * s2 + 1];
                 const float v0 = activate<T, ACT>(__builtin_fmaf(lo[0], osc, b0.x)), v1 = activate<T, ACT>(__builtin_fmaf(lo[1], osc, b0.y));
                 const float v2 = activate<T, ACT>(__builtin_fmaf(lo[2], osc, b0.z)), v3 = activate<T, ACT>(__builtin_fmaf(lo[3], osc, b0.w));
@@ -250,10 +255,10 @@ __global__ __launch_bounds__(512) void conv3x3_tile64_kernel(const ConvP p, cons
         wait_vmcnt<0>();                                             // the next patch (this wave's pieces) and the stores of the tile before
         if constexpr (ABL & 128) ts[2] += __builtin_readcyclecounter() - t0;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int ho = h0 + 2 * wg + r;
+        for (int r = 0; r < RW; ++r) {
+          const int ho = h0 + RW * wg + r;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < FW; ++i) {
             const int wo = w0 + 16 * i + fr;
             if constexpr (ABL & 2) asm volatile("" :: "v"(ov[r][i][0].x), "v"(ov[r][i][0].w), "v"(ov[r][i][1].x), "v"(ov[r][i][1].w));
             else if (ho < p.Ho && wo < p.Wo) {
@@ -292,19 +297,32 @@ bool conv_tile64_legal(const ConvP& p) {
          (long)p.B * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32) < (1L << 22);
 }
 
-template <class T, int ABL = 0> static void launch_tile64_t(const ConvP& p, hipStream_t stream) {
-  constexpr int lds = Tile64Geom::LDS_BYTES;
+template <class T, int ABL = 0, int TWIDTH = 32> static void launch_tile64_g(const ConvP& p, hipStream_t stream) {
+  using G = Tile64Geom<TWIDTH>;
+  constexpr int lds = G::LDS_BYTES;
   static PerDevice pd;
   const int pdi = pd.index();
   if (pd.first(pdi))
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tile64_kernel<T, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tile64_kernel<T, ABL, TWIDTH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int cus = pd.cu_count(pdi);
   Tile64Aux a{};
-  a.tx = (p.Wo + Tile64Geom::TW - 1) / Tile64Geom::TW; a.tiles = ((p.Ho + Tile64Geom::TH - 1) / Tile64Geom::TH) * a.tx; a.total = p.B * a.tiles;
+  a.tx = (p.Wo + G::TW - 1) / G::TW; a.tiles = ((p.Ho + G::TH - 1) / G::TH) * a.tx; a.total = p.B * a.tiles;
   a.inv_tiles = 1.0f / (float)a.tiles; a.inv_tx = 1.0f / (float)a.tx;
   const int grid = std::max(8, std::min(cus, (a.total + 1) / 2) & ~7);   // persistent, one block per CU, two tiles or more per block (one per group), the same number of walkers on every XCD
-  note_launch("conv3x3_tile64", conv3x3_tile64_kernel<T, ABL>, (long)a.total, 512, lds, grid);
-  hipLaunchKernelGGL((conv3x3_tile64_kernel<T, ABL>), dim3(grid), dim3(512), lds, stream, p, a);
+  note_launch("conv3x3_tile64", conv3x3_tile64_kernel<T, ABL, TWIDTH>, (long)a.total, 512, lds, grid);
+  hipLaunchKernelGGL((conv3x3_tile64_kernel<T, ABL, TWIDTH>), dim3(grid), dim3(512), lds, stream, p, a);
+}
+
+// the geometry with fewer tiles, 16 x 16 on a tie (its patch is 324 pixels against 340: 162 against 173 us at 160 x 160, 44.5 against 48.8 at 80 x 80,
+// B = 64, profiles/r06q_tile64.txt); CLEARCAM_TILE64_W=32 / 16 forces one (tests, A/B)
+template <class T, int ABL = 0> static void launch_tile64_t(const ConvP& p, hipStream_t stream) {
+  static const int env_w = [] { const char* e = getenv("CLEARCAM_TILE64_W"); return e ? atoi(e) : 0; }();
+  const int forced = g_tile64_w >= 0 ? g_tile64_w : env_w;      // cc_dev_set("tile64_w", 32 / 16 / -1)
+  const long t32 = (long)((p.Ho + 7) / 8) * ((p.Wo + 31) / 32), t16 = (long)((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
+  if constexpr (ABL == 0) {
+    if (forced == 16 || (forced != 32 && t16 <= t32)) { launch_tile64_g<T, 0, 16>(p, stream); return; }
+  }
+  launch_tile64_g<T, ABL, 32>(p, stream);
 }
 
 void launch_conv_tile64(int dt, const ConvP& p, hipStream_t stream) {

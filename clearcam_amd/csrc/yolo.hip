@@ -458,7 +458,7 @@ struct Builder {
     return dev ? getenv(name) : nullptr;
   }
   // Round 6: at hidden width 64 the layer-at-a-time path has caught up wherever conv_tile64.hip takes the block's two 3x3 64 -> 64 convs (one round of its
-  // 8 x 32 tiles: B >= 9 at 80x80, unsplit 3x3 weights) - whole step, B = 64, f16h, twice each: 6582 / 6582 frames/s against 6531 / 6452 fused
+  // 8 x 32 tiles: B >= 11 at 80x80, unsplit 3x3 weights) - whole step, B = 64, f16h, twice each: 6582 / 6582 frames/s against 6531 / 6452 fused
   // (profiles/r06x_fuse_csp.txt).  Level 2 (default) therefore fuses hidden 64 only below that; 3 = always (the round-2..5 behaviour).  Both forms
   // produce the same bits (test_fused_csp_equals_unfused), so the choice may depend on the batch.
   bool fuse_csp(View in, int hid, int index, const std::string& r) {
@@ -468,7 +468,8 @@ struct Builder {
     if (level == 2 && hid == 64 && !pconv({r + ".m.list.0.cv1.conv"}, {1}).split) {
       const Buf& ib = P->bufs[in.buf];
       const char* t64 = getenv("CLEARCAM_TILE64");
-      if (!(t64 && atoi(t64) == 0) && (long)P->B * ((ib.H + 7) / 8) * ((ib.W + 31) / 32) >= 256) return false;
+      const long per_frame = std::min((long)((ib.H + 7) / 8) * ((ib.W + 31) / 32), (long)((ib.H + 15) / 16) * ((ib.W + 15) / 16));   // conv_mfma.hip's rule for conv_tile64
+      if (!(t64 && atoi(t64) == 0) && (long)P->B * per_frame >= 256 && per_frame * 256 * 4 <= (long)ib.H * ib.W * 5) return false;
     }
     const char* only = dev_env("CLEARCAM_CSP_ONLY");                // development: fuse just this block (csp_debug.py)
     if (only && atoi(only) != index) return false;
@@ -1149,7 +1150,7 @@ namespace cc { void set_error(const std::string& m) { g_err = m; } }
 namespace cc { extern int g_phase_flags_override; }   // conv_phase.hip
 namespace cc { extern int g_stream_flags; }           // conv_stream.hip
 namespace cc { extern int g_stream_abl; }             // conv_stream.hip
-namespace cc { extern int g_tile64_abl; }             // conv_tile64.hip
+namespace cc { extern int g_tile64_abl, g_tile64_w; }  // conv_tile64.hip
 namespace cc { extern int g_stream_override; }        // conv_mfma.hip: -1 = CLEARCAM_STREAM / default, 0 / 1 = streaming 1x1 kernel off / on
 
 extern "C" {
@@ -1773,6 +1774,7 @@ int cc_dev_set(const char* key, int value) {
   else if (std::string(key) == "stream_abl") cc::g_stream_abl = value;
   else if (std::string(key) == "stream_flags") cc::g_stream_flags = value;
   else if (std::string(key) == "tile64_abl") cc::g_tile64_abl = value;
+  else if (std::string(key) == "tile64_w") cc::g_tile64_w = value;
   else throw cc::Error(-22, std::string("cc_dev_set: unknown key ") + key);
   CC_API_END
 }

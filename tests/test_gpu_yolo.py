@@ -266,10 +266,11 @@ TILE64_CASES = [
 ]
 
 
+@pytest.mark.parametrize("width", [32, 16])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("act", [1, 0])
 @pytest.mark.parametrize("case", TILE64_CASES, ids=[c[0] for c in TILE64_CASES])
-def test_tile64_3x3_equals_generic(case, act, dtype):
+def test_tile64_3x3_equals_generic(case, act, dtype, width):
     """Variant 12 (weights resident in LDS in fragment order, double-buffered 10 x 34 patches, hand-pipelined taps, accumulator rows permuted
     for 16-byte stores) against torch and, bit for bit, against the generic tile kernel: same MFMA, same (tap, channel) walk, same epilogue."""
     _, B, H, W_ = case
@@ -277,7 +278,14 @@ def test_tile64_3x3_equals_generic(case, act, dtype):
     x = torch.randn(B, 64, H, W_, generator=g)
     w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
     b = torch.randn(64, generator=g) * 0.1
-    got = conv_hip(x, w, b, 1, 1, act, dtype, force_direct=12)
+    L = _lib.lib()
+    _lib.check(L.cc_dev_set(b"tile64_w", width))                       # 8 x 32-pixel tiles / 16 x 16 (the launcher otherwise takes whichever covers the map with fewer)
+    try:
+        got = conv_hip(x, w, b, 1, 1, act, dtype, force_direct=12)
+        wg = torch.randn(64, 16, 3, 3, generator=g) / 12.0
+        got_grouped = conv_hip(x, wg, b, 1, 4, act, dtype, force_direct=12)
+    finally:
+        _lib.check(L.cc_dev_set(b"tile64_w", -1))
     generic = conv_hip(x, w, b, 1, 1, act, dtype, force_direct=2)
     assert torch.equal(got, generic)
     ref = F.conv2d(x.to(TDT[dtype]).float(), w.to(TDT[dtype]).float(), b, padding=1)
@@ -285,8 +293,7 @@ def test_tile64_3x3_equals_generic(case, act, dtype):
         ref = F.silu(ref)
     assert float((got - ref).abs().max() / ref.abs().max()) <= TOL[dtype]
     # the grouped form DDetect's box branch uses (four groups, densified to block-diagonal weights by the caller)
-    wg = torch.randn(64, 16, 3, 3, generator=g) / 12.0
-    assert torch.equal(conv_hip(x, wg, b, 1, 4, act, dtype, force_direct=12), conv_hip(x, wg, b, 1, 4, act, dtype, force_direct=2))
+    assert torch.equal(got_grouped, conv_hip(x, wg, b, 1, 4, act, dtype, force_direct=2))
 
 
 def test_detect_same_bits_with_and_without_stream_kernel():
@@ -1064,8 +1071,8 @@ np.savez(out, **d)
     ("c", 608, "f16s", 608, 608, 2, "2", 6),      # ... ragged tiles
     ("c", 640, "f16h", 640, 640, 1, "2", 6),      # round 5: two planes in the 1x1 convs only (the four backbone blocks), one plane everywhere (the two neck blocks)
     ("c", 608, "f16h", 608, 608, 2, "2", 6),      # ... ragged tiles
-    ("c", 640, "f16h", 640, 640, 10, "2", 2),     # round 6: from one round of conv_tile64's tiles on (B >= 9 at 80 x 80) level 2 leaves hidden width 64 to the four launches ...
-    ("c", 640, "f16h", 640, 640, 10, "3", 6),     # ... level 3 fuses it at every batch size
+    ("c", 640, "f16h", 640, 640, 11, "2", 2),     # round 6: from one round of conv_tile64's tiles on (25 per frame at 80 x 80: B >= 11) level 2 leaves hidden width 64 to the four launches ...
+    ("c", 640, "f16h", 640, 640, 11, "3", 6),     # ... level 3 fuses it at every batch size
 ])
 def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fused):
     """csp_fused_kernel (cv1|cv2, RepConvN 3x3, 3x3 + shortcut, cv3 of a RepNCSP in one launch, intermediates in LDS) against the
@@ -1090,7 +1097,7 @@ def test_fused_csp_equals_unfused(tmp_path, size, res, dtype, H, W, B, level, fu
 
 
 def test_tile64_in_the_detector_same_bits(tmp_path):
-    """The persistent 3x3 64 -> 64 tile kernel inside the detector (ten frames: one round of its tiles at 80 x 80 and 160 x 160), layer at a time so that
+    """The persistent 3x3 64 -> 64 tile kernel inside the detector (eleven frames: one round of its tiles at 80 x 80 and 160 x 160), layer at a time so that
     it also takes the RepNBottleneck convs that carry the shortcut (16-bit residual added after the activation), against the same plan with
     CLEARCAM_TILE64=0 (wave-autonomous kernel, register epilogue): block outputs, P3-P5 and detections identical."""
     import subprocess
@@ -1099,7 +1106,7 @@ def test_tile64_in_the_detector_same_bits(tmp_path):
     for t64 in ("0", "1"):
         path = str(tmp_path / f"t64_{t64}.npz")
         env = dict(os.environ, CLEARCAM_TILE64=t64, CLEARCAM_FUSE_CSP="0", CLEARCAM_TAP_CSP="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        subprocess.run([sys.executable, "-c", _CSP_SCRIPT, "c", "640", "f16h", "640", "640", "10", path], check=True, env=env)
+        subprocess.run([sys.executable, "-c", _CSP_SCRIPT, "c", "640", "f16h", "640", "640", "11", path], check=True, env=env)
         outs.append(np.load(path))
     a, b = outs
     for n in [n for n in a.files if n.startswith("csp")] + ["p3", "p4", "p5", "det"]:

@@ -7,7 +7,7 @@ from clearcam_amd import _lib
 L = _lib.lib()
 names = {12: "tile64", 8: "wave", 4: "ws", 2: "generic", 0: "auto"}
 print("shape (B H W) f16 | " + " ".join(f"{n:>8}" for n in names.values()) + "   (us per launch, 20 iterations, 3 rounds interleaved: min)")
-for (B, H, W) in [(64, 160, 160), (64, 80, 80), (16, 160, 160), (8, 160, 160), (4, 160, 160), (2, 160, 160), (1, 160, 160), (8, 80, 80)]:
+for (B, H, W) in [(64, 160, 160), (64, 80, 80), (64, 40, 40), (16, 160, 160), (16, 80, 80)]:
     best = {v: float("inf") for v in names}
     for _ in range(3):
         for v in names:
