@@ -132,7 +132,9 @@ int cc_attn_bench(int dtype, int B, int L, int H, int causal, int abl, int iters
 int cc_round_weights(int dtype, const float* w, int64_t cout, int64_t cin, int64_t k, float* out);
 /* Diagnostic (kernel tuning): set a process-wide tuning switch at run time so that one process can A/B kernel variants.
  * key "phase_flags": the CLEARCAM_PHASE_FLAGS bit set of the eight-wave kernel (-1 = back to the environment / default);
- * key "stream": the weights-resident streaming 1x1 kernel off (0) / on (1) / as CLEARCAM_STREAM says (-1).
+ * key "stream": the weights-resident streaming 1x1 kernel off (0) / on (1) / as CLEARCAM_STREAM says (-1);
+ * key "tile64_w": tile geometry of the 3x3 64 -> 64 tile kernel, 32 (8 x 32 pixels) / 16 (16 x 16) / -1 (its own rule);
+ * keys "stream_abl", "stream_flags", "tile64_abl": timing ablations / flag bits of development builds (no effect otherwise).
  * Plans already built keep the launches they were built with.  Not part of the drop-in surface. */
 int cc_dev_set(const char* key, int value);
 
