@@ -12,7 +12,7 @@ shapes = {}
 for r in rows:
     key = (int(float(r["M"])), int(r["Cin"]), int(r["Cout"]), int(r["ks"]), int(r["stride"]))
     shapes.setdefault(key, [0, 0.0]); shapes[key][0] += 1; shapes[key][1] += float(r["ms"])
-names = {0: "auto", 91: "128x32/4", 93: "128x64/3", 95: "64x32/4", 96: "32x32/6", 97: "32x32/4"}
+names = {0: "auto", 91: "128x32/4", 93: "128x64/3", 95: "64x32/4", 97: "32x32/4", 6: "big128", 7: "8-wave", 2: "generic"}
 print("shape (M Cin Cout k s) x n, in-plan us | " + " ".join(f"{n:>9}" for n in names.values()))
 tot = {v: 0.0 for v in names}; tot_best = 0.0
 for (M, Cin, Cout, ks, st), (n, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
