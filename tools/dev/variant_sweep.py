@@ -14,7 +14,7 @@ for r in rows:
     M, Cin, Cout, ks, st = int(float(r["M"])), int(r["Cin"]), int(r["Cout"]), int(r["ks"]), int(r["stride"])
     key = (M, Cin, Cout, ks, st)
     shapes.setdefault(key, [0, 0.0]); shapes[key][0] += 1; shapes[key][1] += float(r["ms"])
-names = {0: "auto", 2: "generic", 3: "halo", 4: "ws", 5: "big256", 6: "big128", 7: "phase", 77: "persist", 8: "wave", 91: "s32/4", 92: "s32/6", 93: "s64/3"}
+names = {0: "auto", 2: "generic", 3: "halo", 4: "ws", 5: "big256", 6: "big128", 7: "phase", 77: "persist", 8: "wave", 10: "stream", 12: "tile64", 93: "s64/3"}
 print("shape (M Cin Cout k s) x n, in-plan us | " + " ".join(f"{n:>7}" for n in names.values()))
 tot_auto = tot_best = 0.0
 for (M, Cin, Cout, ks, st), (n, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
