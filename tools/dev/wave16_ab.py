@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from clearcam_amd import _lib
 L = _lib.lib()
 shapes = [(1, 64, 80, 256, 256, 3, 1), (1, 64, 40, 256, 256, 3, 1), (1, 64, 40, 1024, 512, 1, 1), (1, 64, 80, 1024, 256, 1, 1), (1, 255, 16, 1024, 4096, 1, 1), (1, 255, 16, 4096, 1024, 1, 1)]
-names = {0: "auto", 7: "8-wave", 14: "16-wave", 5: "big256"}
+names = {7: "8-wave", 14: "16w 64KBx2", 15: "16w 32KBx4"}
 for (dt, B, H, Cin, Cout, k, st) in shapes:
     best = {v: float("inf") for v in names}
     for _ in range(3):
